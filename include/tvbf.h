@@ -1,0 +1,120 @@
+/*
+ * tvbf.h -- C ABI of the MI355X (gfx950) similarity / top-K library.
+ *
+ * The reference project is pure Python and has no FFI for this path; its
+ * boundary is the Python call surface of
+ *   tvbingefriend_recommendation_service/ml/similarity_computer.py:12-190,
+ *   scripts/populate_database.py:85-259 and
+ *   tvbingefriend_recommendation_service/services/content_based_service.py:113-338.
+ * Each entry point below names the reference lines whose arithmetic it
+ * replaces.  A Python binding (ctypes) is what a maintainer of the reference
+ * would add; see INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C, no C++ or torch types; every pointer marked "device" is a
+ *     caller-owned HIP device pointer (e.g. torch tensor.data_ptr()), every
+ *     pointer marked "host" is ordinary host memory read during the call;
+ *   - every function returns 0 on success or a negative TVBF_E_* code;
+ *     tvbf_last_error() returns a thread-local message for the last failure;
+ *   - all device work is enqueued on `stream` (a hipStream_t passed as
+ *     void*; NULL = the default stream); the caller synchronises;
+ *   - the library allocates no device memory: scratch comes in through the
+ *     `workspace` argument, sized by tvbf_topk_workspace_bytes();
+ *   - no global mutable state: concurrent calls from different host threads
+ *     on different streams/devices are safe.
+ */
+#ifndef TVBF_H
+#define TVBF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TVBF_OK 0
+#define TVBF_E_BAD_ARG (-1)   /* null pointer, negative size, k out of range ... */
+#define TVBF_E_BAD_SHAPE (-2) /* alignment / leading-dimension / workspace size  */
+#define TVBF_E_HIP (-3)       /* a HIP runtime call failed                       */
+
+#define TVBF_MAX_BLOCKS 8 /* feature blocks per row (genre, text, platform, ...) */
+#define TVBF_MAX_K 100    /* neighbours per show (bounded by the 160 KiB LDS of a CU) */
+
+/* Library version: major*10000 + minor*100 + patch. */
+int tvbf_version(void);
+
+/* Thread-local description of the last error returned on this thread. */
+const char* tvbf_last_error(void);
+
+/*
+ * K1 -- block-wise row L2 normalisation and weighting.
+ * Replaces sklearn's normalize() inside every cosine_similarity call of
+ * ml/similarity_computer.py:41,58,86 and scripts/populate_database.py:180-186,
+ * and folds the hybrid weights of ml/similarity_computer.py:112-124 into the
+ * features: Z[i, off[b]:off[b+1]] = scale[b] * X[i, off[b]:off[b+1]] / norm_b(i)
+ * where norm_b(i) < 10*FLT_EPSILON is replaced by 1 (all-zero blocks stay zero).
+ * With scale[b] = sqrt(weight_b), Z @ Z^T is the hybrid similarity matrix.
+ * Columns [d, ldz) of Z are zero-filled.
+ *
+ *   X              device, n x d fp32, row stride ldx floats
+ *   block_offsets  host, nb+1 ascending ints, [0] = 0, [nb] = d
+ *   block_scales   host, nb floats
+ *   Z              device, n rows, row stride ldz >= d floats (may alias X if ldz == ldx)
+ */
+int tvbf_normalize_blocks_f32(const float* X, int64_t n, int64_t d, int64_t ldx,
+                              const int32_t* block_offsets, const float* block_scales, int nb,
+                              float* Z, int64_t ldz, void* stream);
+
+/*
+ * Bytes of device workspace tvbf_cosine_topk_f32 needs for these sizes on the
+ * current device.  Never fails for valid sizes; returns 0 for invalid ones.
+ */
+size_t tvbf_topk_workspace_bytes(int64_t nq, int64_t n, int64_t d, int k);
+
+/*
+ * K2+K3+K4 -- all-pairs similarity of nq query rows against n rows, fused with
+ * a per-row top-K so that the nq x n score matrix never reaches memory.
+ * Replaces, per query row i: the score row of scripts/populate_database.py:180-192
+ * (= row i of ml/similarity_computer.py:122-124), the descending argsort of
+ * :195 and the walk of :198-218 (skip self by index, stop below min_similarity,
+ * stop at k); also services/content_based_service.py:206-234.
+ *
+ *   score(i, j) = sum_c Zq[i, c] * Zall[j, c]       (fp32 MFMA, fp32 accumulate)
+ *   kept        = the k largest scores with score >= min_similarity, excluding
+ *                 column q_row0 + i when exclude_self != 0; ordered by score
+ *                 descending, equal scores by column index ascending.
+ *
+ *   Zq          device, nq x d fp32, row stride ld (normally Zall + q_row0*ld)
+ *   q_row0      global row index of Zq[0] (for self exclusion; rows of a shard)
+ *   Zall        device, n x d fp32, row stride ld
+ *   d, ld       multiples of 4 (16-byte aligned rows); pointers 16-byte aligned
+ *   k           1..TVBF_MAX_K
+ *   out_idx     device, nq x k int32, unused slots = -1
+ *   out_score   device, nq x k fp32,  unused slots = 0
+ *   out_count   device, nq int32, number of kept neighbours per row
+ *   workspace   device, >= tvbf_topk_workspace_bytes(nq, n, d, k) bytes, 16-byte aligned
+ */
+int tvbf_cosine_topk_f32(const float* Zq, int64_t nq, int64_t q_row0, const float* Zall, int64_t n,
+                         int64_t d, int64_t ld, int k, float min_similarity, int exclude_self,
+                         int32_t* out_idx, float* out_score, int32_t* out_count, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
+/*
+ * K5 -- per-block cosine of every kept pair.
+ * Replaces the component-score look-ups of scripts/populate_database.py:214-216
+ * and services/content_based_service.py:227-229.
+ * out_comp[i, s, b] = dot(Zq[i, blk b], Zall[idx[i, s], blk b]) / scale[b]^2
+ * for idx >= 0, and 0 for unused slots or when scale[b] == 0.
+ *
+ *   idx       device, nq x k int32 as produced by tvbf_cosine_topk_f32
+ *   out_comp  device, nq x k x nb fp32
+ */
+int tvbf_component_scores_f32(const float* Zq, int64_t nq, const float* Zall, int64_t n, int64_t ld,
+                              const int32_t* block_offsets, const float* block_scales, int nb,
+                              const int32_t* idx, int k, float* out_comp, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TVBF_H */

@@ -1,0 +1,167 @@
+"""GPU parity tests of the HIP kernels (through the C ABI) against the float64 oracle."""
+
+from __future__ import annotations
+
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import similarity_oracle as so
+from parity import SCORE_TOL, check_topk_against_golden, check_topk_against_scores
+from synth import dense_gaussian, hybrid_like_blocks
+
+pytestmark = pytest.mark.gpu
+
+
+def _to_np(t):
+    return t.detach().cpu().numpy()
+
+
+def _run_topk(pkg, device, blocks, weights, k, min_similarity, q_row0=0, nq=None, exclude_self=True):
+    """blocks: list of float arrays (n, d_b); returns (TopK on host, z on device, offsets, scales)."""
+    import torch
+
+    from tvbingefriend_recommendation_service_amd import engine
+
+    x = np.ascontiguousarray(np.hstack([np.asarray(b, dtype=np.float32) for b in blocks]))
+    offsets = np.concatenate([[0], np.cumsum([b.shape[1] for b in blocks])]).astype(int).tolist()
+    scales = [float(np.sqrt(w)) for w in weights]
+    xd = torch.from_numpy(x).to(device)
+    z = engine.normalize_blocks(xd, offsets, scales)
+    n = x.shape[0]
+    top = engine.cosine_topk(z, k, min_similarity, q_row0=q_row0, nq=nq, exclude_self=exclude_self)
+    torch.cuda.synchronize()
+    return top, z, offsets, scales
+
+
+def _oracle_h(blocks, weights):
+    z = so.build_z([np.asarray(b, dtype=np.float32).astype(np.float64) for b in blocks], weights)
+    return z @ z.T, z
+
+
+@pytest.mark.parametrize(
+    "n,d,k",
+    [(1000, 96, 20), (130, 4, 1), (257, 36, 50), (129, 100, 100), (64, 32, 20), (3, 8, 2), (1, 8, 5),
+     (2048, 512, 20)],
+)
+def test_dense_matches_oracle(pkg, device, n, d, k):
+    x = dense_gaussian(n, d, seed=1000 + n + d)
+    top, *_ = _run_topk(pkg, device, [x], [1.0], k, -1.0)
+    h, _ = _oracle_h([x], [1.0])
+    exact = check_topk_against_scores(h, 0, k, -1.0, _to_np(top.idx), _to_np(top.score), _to_np(top.count),
+                                      what=f"dense {n}x{d} k={k}")
+    assert exact > 0.9 * min(k, max(n - 1, 0)) * n or n < 4
+
+
+def test_normalize_matches_oracle(pkg, device):
+    import torch
+
+    from tvbingefriend_recommendation_service_amd import engine
+
+    rng = np.random.default_rng(5)
+    g = (rng.random((333, 7)) < 0.3).astype(np.float32)
+    t = np.abs(rng.standard_normal((333, 61))).astype(np.float32)
+    m = rng.standard_normal((333, 5)).astype(np.float32)
+    g[10] = 0
+    t[11] = 0
+    m[12] = 0
+    t[13] *= 1e-9  # below sklearn's guard of 10*eps: divided by 1, stays tiny
+    x = np.hstack([g, t, m])
+    z = engine.normalize_blocks(torch.from_numpy(x).to(device), [0, 7, 68, 73],
+                                [np.sqrt(0.4), np.sqrt(0.5), np.sqrt(0.1)])
+    torch.cuda.synchronize()
+    zz = _to_np(z)
+    assert zz.shape == (333, 96)
+    assert np.all(zz[:, 73:] == 0)
+    ref = np.hstack([np.sqrt(w) * so.l2_normalize_rows(b) for b, w in ((g, 0.4), (t, 0.5), (m, 0.1))])
+    assert np.abs(zz[:, :73] - ref).max() <= 2e-7
+    assert np.all(zz[10, :7] == 0) and np.all(zz[11, 7:68] == 0) and np.all(zz[12, 68:73] == 0)
+
+
+def test_hybrid_ties_min_similarity_and_components(pkg, device):
+    from tvbingefriend_recommendation_service_amd import engine
+
+    n = 1500
+    g, t, p, ty, la = hybrid_like_blocks(n, seed=77, d_genre=24, d_text=200)
+    blocks, weights = [g, t, np.hstack([p, ty, la])], [0.4, 0.5, 0.1]
+    top, z, offsets, scales = _run_topk(pkg, device, blocks, weights, 20, 0.1)
+    h, zo = _oracle_h(blocks, weights)
+    idx, score, count = _to_np(top.idx), _to_np(top.score), _to_np(top.count)
+    check_topk_against_scores(h, 0, 20, 0.1, idx, score, count, what="hybrid ties")
+    # rows without genres and text can only reach 0.1 (metadata): at or below the threshold
+    import torch
+
+    comp = engine.component_scores(z, offsets, scales, top.idx)
+    torch.cuda.synchronize()
+    comp = _to_np(comp)
+    for b, blk in enumerate(blocks):
+        bn = so.l2_normalize_rows(np.asarray(blk, dtype=np.float64))
+        for r in range(0, n, 37):
+            c = count[r]
+            ref = bn[r] @ bn[idx[r, :c]].T
+            assert np.abs(comp[r, :c, b] - ref).max(initial=0) <= SCORE_TOL
+            assert np.all(comp[r, c:, b] == 0)
+
+
+def test_row_shard_matches_full(pkg, device):
+    """Query rows [q_row0, q_row0+nq) of a shard give the same lists as the full run, bit for bit."""
+    n, d, k = 700, 64, 20
+    x = dense_gaussian(n, d, seed=9)
+    full, *_ = _run_topk(pkg, device, [x], [1.0], k, -1.0)
+    part, *_ = _run_topk(pkg, device, [x], [1.0], k, -1.0, q_row0=300, nq=250)
+    assert np.array_equal(_to_np(full.idx)[300:550], _to_np(part.idx))
+    assert np.array_equal(_to_np(full.score)[300:550], _to_np(part.score))
+    assert np.array_equal(_to_np(full.count)[300:550], _to_np(part.count))
+
+
+def test_edge_cases(pkg, device):
+    # N < K: every other show is kept, rest padded
+    x = dense_gaussian(5, 16, seed=3)
+    top, *_ = _run_topk(pkg, device, [x], [1.0], 20, -1.0)
+    assert _to_np(top.count).tolist() == [4] * 5
+    # everything below the threshold: no neighbours at all
+    top, *_ = _run_topk(pkg, device, [x], [1.0], 20, 1.5)
+    assert _to_np(top.count).tolist() == [0] * 5 and np.all(_to_np(top.idx) == -1)
+    # duplicates keep score 1.0 and are excluded by index only; zero rows score 0 with everything
+    y = np.zeros((6, 8), np.float32)
+    y[0] = y[1] = y[2] = [1, 2, 3, 4, 0, 0, 0, 0]
+    y[3] = [0, 0, 0, 0, 1, 0, 0, 0]
+    top, *_ = _run_topk(pkg, device, [y], [1.0], 3, 0.0)
+    idx, score, count = _to_np(top.idx), _to_np(top.score), _to_np(top.count)
+    assert idx[0].tolist() == [1, 2, 3] and np.allclose(score[0, :2], 1.0, atol=1e-6) and score[0, 2] == 0
+    assert idx[1].tolist() == [0, 2, 3]
+    assert idx[4].tolist() == [0, 1, 2] and np.all(score[4] == 0) and count[4] == 3
+    # exclude_self off: the diagonal comes first
+    top, *_ = _run_topk(pkg, device, [y], [1.0], 2, 0.5, exclude_self=False)
+    assert _to_np(top.idx)[0].tolist() == [0, 1] and _to_np(top.idx)[3].tolist() == [3, -1]
+
+
+@pytest.mark.parametrize("name", ["dense_512x64", "dense_2048x512"])
+@pytest.mark.parametrize("k", [20, 50])
+def test_golden_dense(pkg, device, name, k):
+    g = load_golden(name)
+    n, d, seed = int(g["n"]), int(g["d"]), int(g["seed"])
+    x = dense_gaussian(n, d, seed)
+    assert hashlib.sha256(x.tobytes()).hexdigest() == str(g["x_sha256"]), "input generator drifted"
+    top, *_ = _run_topk(pkg, device, [x], [1.0], k, -1.0)
+    xn = so.l2_normalize_rows(x.astype(np.float64))
+    exact = check_topk_against_golden(
+        g[f"idx_k{k}"], g[f"sorted_scores_k{k}"], k, _to_np(top.idx), _to_np(top.score), _to_np(top.count),
+        pair_score=lambda r, cols: xn[r] @ xn[cols].T, what=f"{name} k={k}")
+    assert exact >= 0.99 * n * k  # nearly every rank is separated by more than the tolerance
+
+
+def test_golden_hybrid(pkg, device):
+    g = load_golden("hybrid_2048")
+    n, seed, k = int(g["n"]), int(g["seed"]), int(g["k"])
+    feats = hybrid_like_blocks(n, seed, d_genre=24, d_text=200, as_features=True)
+    gen = np.asarray(feats["genre_features"])
+    assert hashlib.sha256(np.ascontiguousarray(gen).tobytes()).hexdigest() == str(g["genre_sha256"])
+    blocks, weights = so.hybrid_blocks(feats, *g["weights"].tolist(), variant="computer")
+    top, z, offsets, scales = _run_topk(pkg, device, blocks, weights, k, float(g["min_similarity"]))
+    zo = so.build_z(blocks, weights)
+    check_topk_against_golden(g["idx"], g["sorted_scores"], k, _to_np(top.idx), _to_np(top.score),
+                              _to_np(top.count), pair_score=lambda r, cols: zo[r] @ zo[cols].T,
+                              min_similarity=float(g["min_similarity"]), what="hybrid_2048")

@@ -1,0 +1,595 @@
+// MI355X (gfx950 / CDNA4) kernels for the batch similarity + top-K path.
+//
+//   normalize_blocks_kernel   block-wise row L2 normalise + weight        (HBM-bound)
+//   cosine_topk_kernel        Z Z^T on fp32 MFMA fused with per-row top-K (MFMA-bound)
+//   topk_finalize_kernel      merge of the per-column-split partial lists
+//   component_scores_kernel   per-block cosines of the kept pairs
+//
+// The C ABI is declared in include/tvbf.h.  No torch types, no allocation.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <float.h>
+
+#include "tvbf.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned long long u64;
+
+// --------------------------------------------------------------------------
+// error reporting
+// --------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                    \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess)                                                            \
+            return fail(TVBF_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));      \
+    } while (0)
+
+// --------------------------------------------------------------------------
+// ordered keys: (score, column) packed so that a larger key is a better
+// neighbour -- higher score first, lower column index among equal scores.
+// --------------------------------------------------------------------------
+__host__ __device__ static inline uint32_t f32_to_ordered(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u);
+}
+__host__ __device__ static inline float ordered_to_f32(uint32_t m) {
+    uint32_t u = (m & 0x80000000u) ? (m ^ 0x80000000u) : ~m;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+__device__ static inline u64 make_key(float score, int col) {
+    return ((u64)f32_to_ordered(score) << 32) | (u64)(0xFFFFFFFFu - (uint32_t)col);
+}
+// A key whose low word is 0 can never be produced by make_key (col < 2^31):
+// it marks an empty slot and carries the acceptance threshold in its high word.
+__host__ __device__ static inline u64 sentinel_key(float min_similarity) {
+    return (u64)f32_to_ordered(min_similarity) << 32;
+}
+
+// --------------------------------------------------------------------------
+// K1: block-wise L2 normalise + scale.  One wavefront per row.
+// --------------------------------------------------------------------------
+struct BlockDesc {
+    int nb;
+    int off[TVBF_MAX_BLOCKS + 1];
+    float scale[TVBF_MAX_BLOCKS];
+};
+
+__device__ static inline float wave_sum(float v) {
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void normalize_blocks_kernel(const float* __restrict__ X, int64_t n,
+                                                               int d, int64_t ldx, BlockDesc bd,
+                                                               float* __restrict__ Z, int64_t ldz) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float* x = X + row * ldx;
+    float* z = Z + row * ldz;
+    for (int b = 0; b < bd.nb; ++b) {
+        const int c0 = bd.off[b], c1 = bd.off[b + 1];
+        float ss = 0.f;
+        for (int c = c0 + lane; c < c1; c += 64) {
+            const float v = x[c];
+            ss = fmaf(v, v, ss);
+        }
+        ss = wave_sum(ss);
+        float nrm = sqrtf(ss);
+        if (nrm < 10.f * FLT_EPSILON) nrm = 1.f;  // all-zero block stays zero
+        const float f = bd.scale[b] / nrm;
+        for (int c = c0 + lane; c < c1; c += 64) z[c] = x[c] * f;
+    }
+    for (int64_t c = d + lane; c < ldz; c += 64) z[c] = 0.f;
+}
+
+// --------------------------------------------------------------------------
+// K2+K4: fused Z Z^T + per-row top-K.
+//
+// Workgroup = 256 threads = 4 wavefronts, one per SIMD.  It owns BM = 128
+// query rows and one contiguous range of column tiles (a "split"); wave w owns
+// query rows 32w..32w+31 for the whole sweep, so per-row state is private to
+// one wave and needs no cross-wave synchronisation.
+//
+// Per column tile (BN = 128 column shows) the wave accumulates a 128 x 32
+// block of scores as four 32x32 MFMA tiles computed TRANSPOSED: the MFMA "A"
+// operand is the column-show fragment and the "B" operand the query fragment,
+// so lane l ends up holding query row (l & 31) in all of its 64 accumulator
+// registers.  The running K-th best score of that row is one register, and a
+// tile is rejected with 32 v_max3 + 1 compare.
+//
+// v_mfma_f32_32x32x2_f32 takes k = (lane >> 5) of a 2-deep step from each
+// lane; one ds_read_b128 supplies four consecutive steps: step i of read t
+// uses k = 8t + i in lanes 0-31 and k = 8t + 4 + i in lanes 32-63 for both
+// operands, so every score is the same fixed-order fp32 fma chain whatever
+// tile, workgroup or GPU computes it.
+//
+// LDS rows are padded to 36 floats (144 B): the sixteen rows of a
+// ds_read_b128 lane group then fall on sixteen different 16-byte bank slots.
+// --------------------------------------------------------------------------
+constexpr int BM = 128;
+constexpr int BN = 128;
+constexpr int BK = 32;
+constexpr int LDT = BK + 4;
+constexpr int TOPK_THREADS = 256;
+
+struct TopkArgs {
+    const float* zq;
+    const float* zall;
+    u64* partial;  // [splits][nq][k]
+    int64_t nq, n, q_row0, ld;
+    int d, k;
+    int row_blocks, splits, col_tiles;
+    float min_similarity;
+    int exclude_self;
+};
+
+__device__ static inline f32x4 load_chunk(const float* p, bool valid) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (valid) v = *reinterpret_cast<const f32x4*>(p);
+    return v;
+}
+
+// Insert the candidates of the active lanes (`cand`) into the unsorted K-entry
+// lists of their query rows.  Lanes l and l+32 share a row, so the two halves
+// of the wave take turns.  `keys` points at this lane's row list, `mink`/`minp`
+// at the row's smallest key and its slot.
+__device__ static inline void insert_candidates(bool cand, float v, int col, u64* keys, u64* mink,
+                                                int* minp, int k, int half) {
+    const u64 key = make_key(v, col);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (cand && half == h) {
+            const u64 mk = *mink;
+            if (key > mk) {
+                keys[*minp] = key;
+                u64 nm = keys[0];
+                int np = 0;
+#pragma nounroll
+                for (int i = 1; i < k; ++i) {
+                    const u64 x = keys[i];
+                    if (x < nm) {
+                        nm = x;
+                        np = i;
+                    }
+                }
+                *mink = nm;
+                *minp = np;
+            }
+        }
+        // the other half must see these LDS writes: same wave, in-order LDS,
+        // only the compiler has to be kept from reordering
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_kernel(TopkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* tileQ = reinterpret_cast<float*>(smem);
+    float* tileC = tileQ + BM * LDT;
+    u64* keys_all = reinterpret_cast<u64*>(tileC + BN * LDT);
+    u64* mink_all = keys_all + (size_t)BM * a.k;
+    int* minp_all = reinterpret_cast<int*>(mink_all + BM);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int half = lane >> 5;
+    const int lrow = wave * 32 + (lane & 31);  // query row inside the workgroup
+
+    const int rb = blockIdx.x % a.row_blocks;
+    const int split = blockIdx.x / a.row_blocks;
+    const int tile_begin = (int)(((int64_t)a.col_tiles * split) / a.splits);
+    const int tile_end = (int)(((int64_t)a.col_tiles * (split + 1)) / a.splits);
+    const int64_t q0 = (int64_t)rb * BM;  // first query row (local to zq)
+
+    // ---- per-row lists ----
+    const float thr0 = a.min_similarity;
+    {
+        const u64 s = sentinel_key(thr0);
+        for (int i = tid; i < BM * a.k; i += TOPK_THREADS) keys_all[i] = s;
+        if (tid < BM) {
+            mink_all[tid] = s;
+            minp_all[tid] = 0;
+        }
+    }
+    u64* my_keys = keys_all + (size_t)lrow * a.k;
+    u64* my_mink = mink_all + lrow;
+    int* my_minp = minp_all + lrow;
+    float thr = thr0;
+
+    // ---- staging geometry: thread -> (row r + 32 i, 16-byte chunk c) ----
+    const int sc = tid & 7;
+    const int sr = tid >> 3;
+    const float* qsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int64_t r = q0 + sr + 32 * i;
+        if (r > a.nq - 1) r = a.nq - 1;
+        qsrc[i] = a.zq + r * a.ld + sc * 4;
+    }
+    float* qdst = tileQ + sr * LDT + sc * 4;
+    float* cdst = tileC + sr * LDT + sc * 4;
+
+    const int nkb = (a.d + BK - 1) / BK;
+    const int total = (tile_end - tile_begin) * nkb;
+
+    f32x4 rq[4], rc[4];
+    auto load_regs = [&](int ct, int kb) {
+        const int kof = kb * BK;
+        const bool valid = (kof + sc * 4) < a.d;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            rq[i] = load_chunk(qsrc[i] + kof, valid);
+            int64_t r = (int64_t)ct * BN + sr + 32 * i;
+            if (r > a.n - 1) r = a.n - 1;
+            rc[i] = load_chunk(a.zall + r * a.ld + sc * 4 + kof, valid);
+        }
+    };
+
+    const float* q_lds = tileQ + lrow * LDT + half * 4;
+    const float* c_lds = tileC + (lane & 31) * LDT + half * 4;
+    float* scratch = tileQ + wave * 32 * LDT;  // this wave's own query rows, free in the epilogue
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    int ct = tile_begin, kb = 0;
+    if (total > 0) load_regs(ct, kb);
+    __syncthreads();  // lists initialised
+
+    for (int it = 0; it < total; ++it) {
+        __syncthreads();  // everyone is done with the previous LDS tile (and epilogue scratch)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(qdst + 32 * i * LDT) = rq[i];
+            *reinterpret_cast<f32x4*>(cdst + 32 * i * LDT) = rc[i];
+        }
+        __syncthreads();
+        // prefetch the next k-block into registers while the MFMAs run
+        int nct = ct, nkbi = kb + 1;
+        if (nkbi == nkb) {
+            nkbi = 0;
+            ++nct;
+        }
+        if (it + 1 < total) load_regs(nct, nkbi);
+
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f32x4 qf = *reinterpret_cast<const f32x4*>(q_lds + t * 8);
+            f32x4 cf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                cf[j] = *reinterpret_cast<const f32x4*>(c_lds + j * 32 * LDT + t * 8);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(cf[j][i], qf[i], acc[j], 0, 0, 0);
+        }
+
+        if (kb == nkb - 1) {
+            // ------------------------- epilogue -------------------------
+            const int64_t col0 = (int64_t)ct * BN;
+            const int64_t grow = a.q_row0 + q0 + lrow;  // global index of this lane's query row
+            // columns past n (last tile only)
+            if (col0 + BN > a.n) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int64_t c = col0 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        if (c >= a.n) acc[j][r] = -INFINITY;
+                    }
+            }
+            // the show itself (by index, whatever its score)
+            if (a.exclude_self && col0 < a.q_row0 + q0 + BM && col0 + BN > a.q_row0 + q0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int64_t c = col0 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        if (c == grow) acc[j][r] = -INFINITY;
+                    }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float m = acc[j][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[j][r]);
+                if (__any(m >= thr)) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) scratch[r * 64 + lane] = acc[j][r];
+#pragma nounroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = scratch[r * 64 + lane];
+                        const bool cand = v >= thr;
+                        if (__any(cand)) {
+                            const int c = (int)col0 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * half;
+                            insert_candidates(cand, v, c, my_keys, my_mink, my_minp, a.k, half);
+                            thr = ordered_to_f32((uint32_t)(*my_mink >> 32));
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        }
+        ct = nct;
+        kb = nkbi;
+    }
+
+    // ---- publish this split's lists ----
+    __syncthreads();
+    for (int i = tid; i < BM * a.k; i += TOPK_THREADS) {
+        const int r = i / a.k;
+        const int64_t qr = q0 + r;
+        if (qr < a.nq) a.partial[((int64_t)split * a.nq + qr) * a.k + (i - r * a.k)] = keys_all[i];
+    }
+}
+
+// --------------------------------------------------------------------------
+// merge of the per-split lists: one wavefront per query row, rank by counting.
+// --------------------------------------------------------------------------
+constexpr int FIN_MAX_KEYS = 1024;  // splits * k
+
+__global__ __launch_bounds__(256) void topk_finalize_kernel(const u64* __restrict__ partial, int64_t nq,
+                                                            int k, int splits, int32_t* __restrict__ out_idx,
+                                                            float* __restrict__ out_score,
+                                                            int32_t* __restrict__ out_count) {
+    __shared__ u64 buf[4][FIN_MAX_KEYS];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= nq) return;
+    u64* b = buf[wave];
+    const int m = splits * k;
+    for (int i = lane; i < m; i += 64) {
+        const int s = i / k;
+        b[i] = partial[((int64_t)s * nq + row) * k + (i - s * k)];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int valid = 0;
+    for (int i = lane; i < m; i += 64) {
+        const u64 me = b[i];
+        if ((uint32_t)me == 0u) continue;  // empty slot
+        ++valid;
+        int rank = 0;
+        for (int j = 0; j < m; ++j) rank += (b[j] > me) ? 1 : 0;
+        if (rank < k) {
+            out_idx[row * k + rank] = (int32_t)(0xFFFFFFFFu - (uint32_t)me);
+            out_score[row * k + rank] = ordered_to_f32((uint32_t)(me >> 32));
+        }
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) valid += __shfl_xor(valid, s, 64);
+    const int cnt = valid < k ? valid : k;
+    for (int i = cnt + lane; i < k; i += 64) {
+        out_idx[row * k + i] = -1;
+        out_score[row * k + i] = 0.f;
+    }
+    if (lane == 0) out_count[row] = cnt;
+}
+
+// --------------------------------------------------------------------------
+// K5: per-block cosines of the kept pairs.  One wavefront per (row, slot).
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void component_scores_kernel(const float* __restrict__ zq, int64_t nq,
+                                                               const float* __restrict__ zall, int64_t n,
+                                                               int64_t ld, BlockDesc bd,
+                                                               const int32_t* __restrict__ idx, int k,
+                                                               float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t pair = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= nq * k) return;
+    const int64_t row = pair / k;
+    const int32_t j = idx[pair];
+    float* o = out + pair * bd.nb;
+    if (j < 0 || j >= n) {
+        if (lane < bd.nb) o[lane] = 0.f;
+        return;
+    }
+    const float* x = zq + row * ld;
+    const float* y = zall + (int64_t)j * ld;
+    for (int b = 0; b < bd.nb; ++b) {
+        float s = 0.f;
+        for (int c = bd.off[b] + lane; c < bd.off[b + 1]; c += 64) s = fmaf(x[c], y[c], s);
+        s = wave_sum(s);
+        const float w = bd.scale[b] * bd.scale[b];
+        if (lane == 0) o[b] = w > 0.f ? s / w : 0.f;
+    }
+}
+
+// --------------------------------------------------------------------------
+// host side
+// --------------------------------------------------------------------------
+struct Plan {
+    int row_blocks, col_tiles, splits;
+    size_t lds_bytes;
+    int wg_per_cu;
+};
+
+static int device_cus() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        return 256;
+    return cus;
+}
+
+static size_t topk_lds_bytes(int k) {
+    return (size_t)(BM + BN) * LDT * sizeof(float) + (size_t)BM * k * 8 + (size_t)BM * 8 + (size_t)BM * 4;
+}
+
+// Column splits trade tail balance (more, shorter workgroups) against repeated
+// list warm-up; every choice gives the same result because the merge applies
+// one total order.
+static Plan make_plan(int64_t nq, int64_t n, int k, int cus) {
+    Plan p;
+    p.row_blocks = (int)((nq + BM - 1) / BM);
+    p.col_tiles = (int)((n + BN - 1) / BN);
+    p.lds_bytes = topk_lds_bytes(k);
+    p.wg_per_cu = p.lds_bytes * 2 <= 160 * 1024 ? 2 : 1;
+    const int64_t slots = (int64_t)cus * p.wg_per_cu;
+    int max_s = FIN_MAX_KEYS / k;
+    if (max_s > 16) max_s = 16;
+    if (max_s > p.col_tiles) max_s = p.col_tiles;
+    if (max_s < 1) max_s = 1;
+    int best = 1;
+    double best_cost = 1e300;
+    for (int s = 1; s <= max_s; ++s) {
+        const int64_t wgs = (int64_t)p.row_blocks * s;
+        const int64_t rounds = (wgs + slots - 1) / slots;
+        const int64_t tiles = (p.col_tiles + s - 1) / s;
+        const double cost = (double)rounds * ((double)tiles + 0.5);  // 0.5 tile ~ warm-up + merge
+        if (cost < best_cost * 0.999) {
+            best_cost = cost;
+            best = s;
+        }
+    }
+    p.splits = best;
+    return p;
+}
+
+static int fill_blocks(BlockDesc* bd, const int32_t* off, const float* scale, int nb, int64_t d) {
+    if (nb < 1 || nb > TVBF_MAX_BLOCKS || !off || !scale)
+        return fail(TVBF_E_BAD_ARG, "nb must be 1..%d and block arrays non-null", TVBF_MAX_BLOCKS);
+    if (off[0] != 0 || off[nb] != d) return fail(TVBF_E_BAD_SHAPE, "block_offsets must run from 0 to d");
+    bd->nb = nb;
+    for (int b = 0; b <= nb; ++b) {
+        if (b && off[b] < off[b - 1]) return fail(TVBF_E_BAD_SHAPE, "block_offsets must be ascending");
+        bd->off[b] = off[b];
+    }
+    for (int b = 0; b < nb; ++b) bd->scale[b] = scale[b];
+    return TVBF_OK;
+}
+
+extern "C" {
+
+int tvbf_version(void) { return 100; }
+
+const char* tvbf_last_error(void) { return g_err; }
+
+int tvbf_normalize_blocks_f32(const float* X, int64_t n, int64_t d, int64_t ldx, const int32_t* block_offsets,
+                              const float* block_scales, int nb, float* Z, int64_t ldz, void* stream) {
+    if (!X || !Z) return fail(TVBF_E_BAD_ARG, "X and Z must be non-null");
+    if (n < 0 || d < 1 || d > INT32_MAX) return fail(TVBF_E_BAD_ARG, "bad n or d");
+    if (ldx < d || ldz < d) return fail(TVBF_E_BAD_SHAPE, "row strides must be >= d");
+    BlockDesc bd;
+    int rc = fill_blocks(&bd, block_offsets, block_scales, nb, d);
+    if (rc) return rc;
+    if (n == 0) return TVBF_OK;
+    const int64_t grid = (n + 3) / 4;
+    if (grid > INT32_MAX) return fail(TVBF_E_BAD_ARG, "n too large");
+    hipLaunchKernelGGL(normalize_blocks_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, X, n,
+                       (int)d, ldx, bd, Z, ldz);
+    HIP_TRY(hipGetLastError());
+    return TVBF_OK;
+}
+
+size_t tvbf_topk_workspace_bytes(int64_t nq, int64_t n, int64_t d, int k) {
+    (void)d;
+    if (nq < 1 || n < 1 || k < 1 || k > TVBF_MAX_K) return 0;
+    const Plan p = make_plan(nq, n, k, device_cus());
+    return (size_t)p.splits * (size_t)nq * (size_t)k * 8;
+}
+
+int tvbf_cosine_topk_f32(const float* Zq, int64_t nq, int64_t q_row0, const float* Zall, int64_t n, int64_t d,
+                         int64_t ld, int k, float min_similarity, int exclude_self, int32_t* out_idx,
+                         float* out_score, int32_t* out_count, void* workspace, size_t workspace_bytes,
+                         void* stream) {
+    if (!Zq || !Zall || !out_idx || !out_score || !out_count)
+        return fail(TVBF_E_BAD_ARG, "null pointer argument");
+    if (nq < 0 || n < 1 || d < 1 || q_row0 < 0) return fail(TVBF_E_BAD_ARG, "bad nq, n, d or q_row0");
+    if (k < 1 || k > TVBF_MAX_K) return fail(TVBF_E_BAD_ARG, "k must be 1..%d", TVBF_MAX_K);
+    if (n > INT32_MAX - BN || d > INT32_MAX - BK) return fail(TVBF_E_BAD_ARG, "n or d too large");
+    if ((d & 3) || (ld & 3) || ld < d) return fail(TVBF_E_BAD_SHAPE, "d and ld must be multiples of 4, ld >= d");
+    if (((uintptr_t)Zq & 15) || ((uintptr_t)Zall & 15)) return fail(TVBF_E_BAD_SHAPE, "Z must be 16-byte aligned");
+    if (min_similarity != min_similarity) return fail(TVBF_E_BAD_ARG, "min_similarity is NaN");
+    if (nq == 0) return TVBF_OK;
+    if (min_similarity < -FLT_MAX) min_similarity = -FLT_MAX;  // -inf marks masked columns
+
+    const Plan p = make_plan(nq, n, k, device_cus());
+    const size_t need = (size_t)p.splits * (size_t)nq * (size_t)k * 8;
+    if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15))
+        return fail(TVBF_E_BAD_SHAPE, "workspace must be 16-byte aligned and >= %zu bytes", need);
+    const int64_t grid = (int64_t)p.row_blocks * p.splits;
+    if (grid > INT32_MAX) return fail(TVBF_E_BAD_ARG, "too many workgroups");
+
+    if (p.lds_bytes > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(cosine_topk_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
+
+    TopkArgs a;
+    a.zq = Zq;
+    a.zall = Zall;
+    a.partial = reinterpret_cast<u64*>(workspace);
+    a.nq = nq;
+    a.n = n;
+    a.q_row0 = q_row0;
+    a.ld = ld;
+    a.d = (int)d;
+    a.k = k;
+    a.row_blocks = p.row_blocks;
+    a.splits = p.splits;
+    a.col_tiles = p.col_tiles;
+    a.min_similarity = min_similarity;
+    a.exclude_self = exclude_self;
+    hipLaunchKernelGGL(cosine_topk_kernel, dim3((unsigned)grid), dim3(TOPK_THREADS), p.lds_bytes,
+                       (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(topk_finalize_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const u64*>(workspace), nq, k, p.splits, out_idx, out_score, out_count);
+    HIP_TRY(hipGetLastError());
+    return TVBF_OK;
+}
+
+int tvbf_component_scores_f32(const float* Zq, int64_t nq, const float* Zall, int64_t n, int64_t ld,
+                              const int32_t* block_offsets, const float* block_scales, int nb, const int32_t* idx,
+                              int k, float* out_comp, void* stream) {
+    if (!Zq || !Zall || !idx || !out_comp) return fail(TVBF_E_BAD_ARG, "null pointer argument");
+    if (nq < 0 || n < 1 || k < 1) return fail(TVBF_E_BAD_ARG, "bad nq, n or k");
+    if (nb < 1 || nb > TVBF_MAX_BLOCKS || !block_offsets)
+        return fail(TVBF_E_BAD_ARG, "nb must be 1..%d", TVBF_MAX_BLOCKS);
+    BlockDesc bd;
+    int rc = fill_blocks(&bd, block_offsets, block_scales, nb, block_offsets[nb]);
+    if (rc) return rc;
+    if (ld < block_offsets[nb]) return fail(TVBF_E_BAD_SHAPE, "ld smaller than the last block offset");
+    if (nq == 0) return TVBF_OK;
+    const int64_t grid = (nq * k + 3) / 4;
+    if (grid > INT32_MAX) return fail(TVBF_E_BAD_ARG, "too many pairs");
+    hipLaunchKernelGGL(component_scores_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, Zq, nq,
+                       Zall, n, ld, bd, idx, k, out_comp);
+    HIP_TRY(hipGetLastError());
+    return TVBF_OK;
+}
+
+}  // extern "C"

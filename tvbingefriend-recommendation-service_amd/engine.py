@@ -1,0 +1,154 @@
+"""Device-side operations of the similarity path on torch tensors.
+
+torch is plumbing here: it owns the HBM buffers and the HIP stream; all
+arithmetic happens in the kernels of csrc/ reached through the C ABI
+(:mod:`native`).  Every function launches on torch's current stream and
+returns without synchronising.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+
+from . import native
+
+LD_ALIGN = 32  # Z rows are padded to a multiple of one k-tile (32 floats = 128 B)
+
+
+def _require_cuda(t: torch.Tensor, name: str, dtype=torch.float32) -> None:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise native.NativeLibraryError(f"{name} must be a tensor on the GPU (there is no CPU path)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+
+
+def _stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def padded_ld(d: int) -> int:
+    return (int(d) + LD_ALIGN - 1) // LD_ALIGN * LD_ALIGN
+
+
+def normalize_blocks(x: torch.Tensor, offsets, scales, out: torch.Tensor | None = None) -> torch.Tensor:
+    """Z[:, blk] = scale_blk * x[:, blk] / ||x[:, blk]|| per row (zero blocks stay zero).
+
+    ``x`` is (n, d) fp32 on the GPU with unit column stride.  Returns (n, ld)
+    with ld = d rounded up to 32 and zero padding columns.
+    """
+    _require_cuda(x, "x")
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("x must be 2-D with contiguous rows")
+    n, d = x.shape
+    if int(offsets[-1]) != d:
+        raise ValueError("last block offset must equal the number of columns")
+    ld = padded_ld(d)
+    if out is None:
+        out = torch.empty((n, ld), dtype=torch.float32, device=x.device)
+    _require_cuda(out, "out")
+    if out.shape != (n, ld) or not out.is_contiguous():
+        raise ValueError(f"out must be a contiguous ({n}, {ld}) tensor")
+    off, sc, nb = native.block_arrays(offsets, scales)
+    lib = native.load()
+    with torch.cuda.device(x.device):
+        rc = lib.tvbf_normalize_blocks_f32(x.data_ptr(), n, d, x.stride(0), off, sc, nb,
+                                           out.data_ptr(), ld, _stream_ptr())
+    native.check(rc, "tvbf_normalize_blocks_f32")
+    return out
+
+
+@dataclass
+class TopK:
+    """Per-row neighbours: idx (nq,k) int32 (-1 = unused), score (nq,k) fp32,
+    count (nq,) int32; rows ordered by score descending, then index ascending."""
+
+    idx: torch.Tensor
+    score: torch.Tensor
+    count: torch.Tensor
+
+
+def topk_workspace_bytes(nq: int, n: int, d: int, k: int, device=None) -> int:
+    lib = native.load()
+    if device is not None and torch.cuda.is_available():
+        with torch.cuda.device(device):
+            return int(lib.tvbf_topk_workspace_bytes(nq, n, d, k))
+    return int(lib.tvbf_topk_workspace_bytes(nq, n, d, k))
+
+
+def cosine_topk(z_all: torch.Tensor, k: int, min_similarity: float, *, q_row0: int = 0,
+                nq: int | None = None, n: int | None = None, exclude_self: bool = True,
+                z_q: torch.Tensor | None = None, workspace: torch.Tensor | None = None,
+                out: TopK | None = None) -> TopK:
+    """Top-k of (z_q @ z_all.T) per query row without materialising the scores.
+
+    ``z_all`` is (rows >= n, ld) fp32; the query rows default to rows
+    ``q_row0 .. q_row0 + nq`` of ``z_all`` (pass ``z_q`` for a separate block).
+    """
+    _require_cuda(z_all, "z_all")
+    if z_all.dim() != 2 or not z_all.is_contiguous():
+        raise ValueError("z_all must be a contiguous 2-D tensor")
+    n = z_all.shape[0] if n is None else int(n)
+    ld = z_all.shape[1]
+    if z_q is None:
+        nq = n - q_row0 if nq is None else int(nq)
+        if q_row0 < 0 or q_row0 + nq > z_all.shape[0]:
+            raise ValueError("query rows outside z_all")
+        zq_ptr = z_all.data_ptr() + q_row0 * ld * 4
+    else:
+        _require_cuda(z_q, "z_q")
+        if z_q.dim() != 2 or not z_q.is_contiguous() or z_q.shape[1] != ld:
+            raise ValueError("z_q must be contiguous with the same row length as z_all")
+        nq = z_q.shape[0] if nq is None else int(nq)
+        zq_ptr = z_q.data_ptr()
+    if not 1 <= n <= z_all.shape[0]:
+        raise ValueError("n outside z_all")
+    if not 1 <= k <= native.TVBF_MAX_K:
+        raise ValueError(f"k must be in 1..{native.TVBF_MAX_K}")
+    dev = z_all.device
+    if out is None:
+        out = TopK(torch.empty((nq, k), dtype=torch.int32, device=dev),
+                   torch.empty((nq, k), dtype=torch.float32, device=dev),
+                   torch.empty((nq,), dtype=torch.int32, device=dev))
+    lib = native.load()
+    with torch.cuda.device(dev):
+        need = int(lib.tvbf_topk_workspace_bytes(max(nq, 1), n, ld, k))
+        if workspace is None:
+            workspace = torch.empty((need + 15) // 16 * 2, dtype=torch.int64, device=dev)
+        ws_bytes = workspace.numel() * workspace.element_size()
+        rc = lib.tvbf_cosine_topk_f32(zq_ptr, nq, q_row0, z_all.data_ptr(), n, ld, ld, k,
+                                      float(min_similarity), 1 if exclude_self else 0,
+                                      out.idx.data_ptr(), out.score.data_ptr(), out.count.data_ptr(),
+                                      workspace.data_ptr(), ws_bytes, _stream_ptr())
+    native.check(rc, "tvbf_cosine_topk_f32")
+    return out
+
+
+def component_scores(z_all: torch.Tensor, offsets, scales, idx: torch.Tensor, *, q_row0: int = 0,
+                     n: int | None = None, z_q: torch.Tensor | None = None) -> torch.Tensor:
+    """Per-block cosines (nq, k, nb) of the kept pairs listed in ``idx``."""
+    _require_cuda(z_all, "z_all")
+    _require_cuda(idx, "idx", torch.int32)
+    if not idx.is_contiguous() or idx.dim() != 2:
+        raise ValueError("idx must be a contiguous (nq, k) tensor")
+    nq, k = idx.shape
+    n = z_all.shape[0] if n is None else int(n)
+    ld = z_all.shape[1]
+    if z_q is None:
+        if q_row0 < 0 or q_row0 + nq > z_all.shape[0]:
+            raise ValueError("query rows outside z_all")
+        zq_ptr = z_all.data_ptr() + q_row0 * ld * 4
+    else:
+        _require_cuda(z_q, "z_q")
+        zq_ptr = z_q.data_ptr()
+    off, sc, nb = native.block_arrays(offsets, scales)
+    if int(offsets[-1]) > ld:
+        raise ValueError("block offsets exceed the row length")
+    out = torch.empty((nq, k, nb), dtype=torch.float32, device=z_all.device)
+    lib = native.load()
+    with torch.cuda.device(z_all.device):
+        rc = lib.tvbf_component_scores_f32(zq_ptr, nq, z_all.data_ptr(), n, ld, off, sc, nb,
+                                           idx.data_ptr(), k, out.data_ptr(), _stream_ptr())
+    native.check(rc, "tvbf_component_scores_f32")
+    return out

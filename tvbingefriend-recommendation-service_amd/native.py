@@ -1,0 +1,118 @@
+"""ctypes binding of the C ABI declared in include/tvbf.h.
+
+The shared library is built in-tree (csrc/libtvbf.so) by :func:`build`.  There
+is no fallback: if the library is missing or a call fails, an exception is
+raised.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from pathlib import Path
+
+CSRC = Path(__file__).resolve().parent / "csrc"
+INCLUDE = Path(__file__).resolve().parent.parent / "include"
+LIB_PATH = CSRC / "libtvbf.so"
+SOURCES = [CSRC / "tvbf_kernels.hip"]
+
+# Every symbol include/tvbf.h declares.
+SYMBOLS = (
+    "tvbf_version",
+    "tvbf_last_error",
+    "tvbf_normalize_blocks_f32",
+    "tvbf_topk_workspace_bytes",
+    "tvbf_cosine_topk_f32",
+    "tvbf_component_scores_f32",
+)
+
+TVBF_MAX_BLOCKS = 8
+TVBF_MAX_K = 100
+
+
+class NativeLibraryError(RuntimeError):
+    """The HIP library is missing, cannot be loaded, or a call into it failed."""
+
+
+def hipcc_command(out: Path) -> list[str]:
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    return [
+        hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+        f"-I{INCLUDE}",
+        # packed fp32 VALU forms are switched off for device code
+        "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",
+        "-o", str(out), *[str(s) for s in SOURCES],
+    ]
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """Compile csrc/*.hip for gfx950 into csrc/libtvbf.so (no GPU needed)."""
+    deps = SOURCES + [INCLUDE / "tvbf.h"]
+    if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= p.stat().st_mtime for p in deps):
+        return LIB_PATH
+    tmp = LIB_PATH.with_suffix(".so.tmp")
+    cmd = hipcc_command(tmp)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise NativeLibraryError(f"hipcc failed ({res.returncode}):\n{' '.join(cmd)}\n{res.stderr}")
+    if verbose:
+        print(res.stderr)
+    os.replace(tmp, LIB_PATH)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load csrc/libtvbf.so and declare the signatures of include/tvbf.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise NativeLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback)"
+        )
+    try:
+        lib = ctypes.CDLL(str(LIB_PATH))
+    except OSError as e:  # pragma: no cover - depends on the box
+        raise NativeLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    c = ctypes
+    i64, i32, f32, vp, sz = c.c_int64, c.c_int32, c.c_float, c.c_void_p, c.c_size_t
+    lib.tvbf_version.restype = c.c_int
+    lib.tvbf_version.argtypes = []
+    lib.tvbf_last_error.restype = c.c_char_p
+    lib.tvbf_last_error.argtypes = []
+    lib.tvbf_normalize_blocks_f32.restype = c.c_int
+    lib.tvbf_normalize_blocks_f32.argtypes = [vp, i64, i64, i64, c.POINTER(i32), c.POINTER(f32), c.c_int,
+                                              vp, i64, vp]
+    lib.tvbf_topk_workspace_bytes.restype = sz
+    lib.tvbf_topk_workspace_bytes.argtypes = [i64, i64, i64, c.c_int]
+    lib.tvbf_cosine_topk_f32.restype = c.c_int
+    lib.tvbf_cosine_topk_f32.argtypes = [vp, i64, i64, vp, i64, i64, i64, c.c_int, f32, c.c_int,
+                                         vp, vp, vp, vp, sz, vp]
+    lib.tvbf_component_scores_f32.restype = c.c_int
+    lib.tvbf_component_scores_f32.argtypes = [vp, i64, vp, i64, i64, c.POINTER(i32), c.POINTER(f32), c.c_int,
+                                              vp, c.c_int, vp, vp]
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().tvbf_last_error().decode("utf-8", "replace")
+        raise NativeLibraryError(f"{what} failed with code {rc}: {msg}")
+
+
+def block_arrays(offsets, scales):
+    """Host arrays (int32 offsets, float scales) in the form the C ABI reads."""
+    nb = len(scales)
+    if len(offsets) != nb + 1:
+        raise ValueError("offsets must have one more entry than scales")
+    if not 1 <= nb <= TVBF_MAX_BLOCKS:
+        raise ValueError(f"1..{TVBF_MAX_BLOCKS} feature blocks are supported, got {nb}")
+    off = (ctypes.c_int32 * (nb + 1))(*[int(o) for o in offsets])
+    sc = (ctypes.c_float * nb)(*[float(s) for s in scales])
+    return off, sc, nb
