@@ -101,6 +101,18 @@ int tvbf_cosine_topk_f32(const float* Zq, int64_t nq, int64_t q_row0, const floa
                          size_t workspace_bytes, void* stream);
 
 /*
+ * K2 alone -- the dense score matrix, for callers that want it whole (small n):
+ * out[i, j] = sum_c Zq[i, c] * Zall[j, c].  With Z one normalised feature block
+ * this is sklearn's cosine_similarity(X) of ml/similarity_computer.py:41,58,86;
+ * with the weighted hybrid Z it is ml/similarity_computer.py:122-124.
+ * Each score is the same fp32 sum as in tvbf_cosine_topk_f32.
+ *
+ *   out   device, nq x n fp32, row stride ldo >= n floats
+ */
+int tvbf_gram_f32(const float* Zq, int64_t nq, const float* Zall, int64_t n, int64_t d, int64_t ld,
+                  float* out, int64_t ldo, void* stream);
+
+/*
  * K5 -- per-block cosine of every kept pair.
  * Replaces the component-score look-ups of scripts/populate_database.py:214-216
  * and services/content_based_service.py:227-229.
@@ -113,6 +125,33 @@ int tvbf_cosine_topk_f32(const float* Zq, int64_t nq, int64_t q_row0, const floa
 int tvbf_component_scores_f32(const float* Zq, int64_t nq, const float* Zall, int64_t n, int64_t ld,
                               const int32_t* block_offsets, const float* block_scales, int nb,
                               const int32_t* idx, int k, float* out_comp, void* stream);
+
+/*
+ * K3 -- weighted hybrid sum of three score matrices (any equal-sized buffers):
+ * out[i] = (wa*a[i] + wb*b[i]) + wc*c[i] in float64, each product and sum
+ * rounded separately, which is bit-for-bit the NumPy expression of
+ * ml/similarity_computer.py:122-124 and services/content_based_service.py:134-138
+ * (the caller divides the weights by their sum first, :112-115 / :133).
+ * All pointers device, `count` doubles each; out may alias an input.
+ */
+int tvbf_weighted_sum3_f64(const double* a, const double* b, const double* c, double wa, double wb,
+                           double wc, double* out, int64_t count, void* stream);
+
+/*
+ * K6 -- statistics of the strict upper triangle (j > i) of an n x n float64
+ * matrix: out5 = {mean, std (ddof 0), min, max, median}; replaces
+ * ml/similarity_computer.py:182-190 (called four times from
+ * scripts/compute_similarities.py:119-131).  min, max and median are exact
+ * (median = mean of the two middle order statistics, found by radix select);
+ * mean and std are float64 sums in a different order than NumPy's pairwise sum.
+ *
+ *   M          device, n x n float64, row stride ld doubles, n >= 2
+ *   out5       device, 5 doubles
+ *   workspace  device, >= tvbf_stats_workspace_bytes() bytes, 8-byte aligned
+ */
+size_t tvbf_stats_workspace_bytes(void);
+int tvbf_upper_tri_stats_f64(const double* M, int64_t n, int64_t ld, double* out5, void* workspace,
+                             size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

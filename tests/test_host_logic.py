@@ -1,0 +1,203 @@
+"""CPU tests of the host side: C-ABI surface, feature packing, row sharding (gloo, 2 ranks)."""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import similarity_oracle as so
+from synth import hybrid_like_blocks
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+# ---------------------------------------------------------------- C ABI ----
+
+def test_library_exports_every_declared_symbol(pkg):
+    from tvbingefriend_recommendation_service_amd import native
+
+    header = (ROOT / "include" / "tvbf.h").read_text()
+    declared = sorted(set(re.findall(r"\b(tvbf_[a-z0-9_]+)\s*\(", header)))
+    assert declared, "no declarations found in include/tvbf.h"
+    assert sorted(native.SYMBOLS) == declared
+    lib = native.load()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} is declared in tvbf.h but not exported"
+    assert lib.tvbf_version() >= 100
+
+
+def test_argument_validation_needs_no_gpu(pkg):
+    """Bad arguments are rejected on the host before any device work."""
+    from tvbingefriend_recommendation_service_amd import native
+
+    lib = native.load()
+    p = ctypes.c_void_p(16)  # never dereferenced: validation fails first
+    rc = lib.tvbf_cosine_topk_f32(p, 4, 0, p, 4, 32, 32, 0, 0.1, 1, p, p, p, p, 1 << 20, None)
+    assert rc == -1 and b"k must be" in lib.tvbf_last_error()
+    rc = lib.tvbf_cosine_topk_f32(p, 4, 0, p, 4, 30, 32, 5, 0.1, 1, p, p, p, p, 1 << 20, None)
+    assert rc == -2 and b"multiples of 4" in lib.tvbf_last_error()
+    rc = lib.tvbf_cosine_topk_f32(None, 4, 0, p, 4, 32, 32, 5, 0.1, 1, p, p, p, p, 1 << 20, None)
+    assert rc == -1
+    rc = lib.tvbf_cosine_topk_f32(p, 4, 0, p, 4, 32, 32, 5, float("nan"), 1, p, p, p, p, 1 << 20, None)
+    assert rc == -1
+    off = (ctypes.c_int32 * 3)(0, 8, 4)
+    sc = (ctypes.c_float * 2)(1.0, 1.0)
+    rc = lib.tvbf_normalize_blocks_f32(p, 4, 4, 4, off, sc, 2, p, 4, None)
+    assert rc == -2
+    rc = lib.tvbf_upper_tri_stats_f64(p, 1, 1, p, p, 1 << 20, None)
+    assert rc == -1 and b"empty" in lib.tvbf_last_error()
+    assert lib.tvbf_topk_workspace_bytes(0, 10, 32, 5) == 0
+    assert lib.tvbf_topk_workspace_bytes(10, 10, 32, 101) == 0
+    assert lib.tvbf_topk_workspace_bytes(1000, 1000, 32, 20) >= 1000 * 20 * 8
+
+
+def test_product_fails_loudly_without_gpu(pkg):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    from tvbingefriend_recommendation_service_amd import engine, native
+    from tvbingefriend_recommendation_service_amd.ml.similarity_computer import SimilarityComputer
+
+    with pytest.raises(native.NativeLibraryError):
+        SimilarityComputer().compute_genre_similarity(np.eye(3))
+    with pytest.raises(native.NativeLibraryError):
+        engine.normalize_blocks(torch.zeros(4, 4), [0, 4], [1.0])
+
+
+# ------------------------------------------------------ feature packing ----
+
+def test_pack_features_layouts(pkg):
+    from tvbingefriend_recommendation_service_amd import features as feat
+
+    f = hybrid_like_blocks(50, seed=1, d_genre=7, d_text=30, as_features=True)
+    x, lay = feat.pack_features(f, 2.0, 3.0, 1.0, "computer")
+    assert x.dtype == np.float32 and x.flags.c_contiguous
+    assert lay.offsets == [0, 8, 40, 72] and lay.widths == [7, 30, 32] and lay.groups == [0, 1, 2]
+    assert lay.weights == pytest.approx([2 / 6, 3 / 6, 1 / 6])
+    assert np.all(x[:, 7] == 0) and np.all(x[:, 38:40] == 0)
+    assert np.array_equal(x[:, :7], np.asarray(f["genre_features"], dtype=np.float32))
+    assert np.array_equal(x[:, 8:38], f["text_features"].toarray().astype(np.float32))
+    x2, lay2 = feat.pack_features(f, 0.4, 0.5, 0.1, "populate")
+    assert lay2.offsets == [0, 8, 40, 64, 72, 80] and lay2.groups == [0, 1, 2, 2, 2]
+    assert lay2.weights == pytest.approx([0.4, 0.5, 0.1 / 3, 0.1 / 3, 0.1 / 3])
+    # the packed, normalised, scaled matrix reproduces the oracle's hybrid matrix
+    for xx, ll, variant in ((x, lay, "computer"), (x2, lay2, "populate")):
+        w = (2.0, 3.0, 1.0) if variant == "computer" else (0.4, 0.5, 0.1)
+        blocks = [xx[:, ll.offsets[b] : ll.offsets[b + 1]].astype(np.float64) for b in range(ll.nb)]
+        z = so.build_z(blocks, ll.weights)
+        zo = so.build_z(*so.hybrid_blocks(f, *w, variant=variant))
+        assert np.abs(z @ z.T - zo @ zo.T).max() <= 1e-7  # fp32 storage of the TF-IDF values
+    with pytest.raises(ValueError):
+        feat.pack_features(f, -0.1, 0.5, 0.6, "populate")[1].scales()
+    with pytest.raises(KeyError):
+        feat.pack_features({"genre_features": np.eye(2)}, 1, 1, 1)
+    assert feat.BlockLayout([0, 4, 8], [4, 4], [0.0, 1.0], [0, 1]).component_scales() == [1.0, 1.0]
+
+
+def test_fold_components(pkg):
+    from tvbingefriend_recommendation_service_amd import features as feat
+
+    lay = feat.BlockLayout([0, 4, 8, 12, 16, 20], [4] * 5, [0.4, 0.5, 0.1, 0.1, 0.1], [0, 1, 2, 2, 2])
+    comp = np.arange(2 * 3 * 5, dtype=np.float32).reshape(2, 3, 5)
+    out = feat.fold_components(comp, lay)
+    assert out.shape == (2, 3, 3)
+    assert np.allclose(out[..., 0], comp[..., 0]) and np.allclose(out[..., 2], comp[..., 2:].mean(axis=-1))
+
+
+# -------------------------------------------------------- row sharding ----
+
+def test_shard_bounds(pkg):
+    from tvbingefriend_recommendation_service_amd.sharding import shard_bounds
+
+    s = [shard_bounds(10, 4, r) for r in range(4)]
+    assert [(x.row0, x.rows) for x in s] == [(0, 3), (3, 3), (6, 3), (9, 1)]
+    assert all(x.per_rank == 3 and x.padded_total == 12 for x in s)
+    s = [shard_bounds(5, 8, r) for r in range(8)]
+    assert sum(x.rows for x in s) == 5 and s[7].rows == 0 and s[7].row0 == 5
+    assert shard_bounds(100_000, 8, 7).row0 == 87_500
+    with pytest.raises(ValueError):
+        shard_bounds(10, 2, 2)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _shard_worker(rank, world, port, n, k, min_sim, ret):
+    """One gloo rank: CPU stand-ins for the two kernels, the real sharding code around them."""
+    import torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    import tvbf_amd  # noqa: F401
+    from tvbingefriend_recommendation_service_amd import engine, sharding
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g, t, p, ty, la = hybrid_like_blocks(n, seed=11, d_genre=12, d_text=40)
+        x = np.hstack([g, t, p, ty, la]).astype(np.float32)
+        offsets, weights = [0, 12, 52, 84], [0.4, 0.5, 0.1]
+        scales = [float(np.sqrt(w)) for w in weights]
+        sh = sharding.shard_bounds(n, world, rank)
+        xs = np.zeros((sh.per_rank, x.shape[1]), np.float32)
+        xs[: sh.rows] = x[sh.row0 : sh.row0 + sh.rows]
+
+        def normalize_fn(xt, off, sc):
+            xx = xt.numpy().astype(np.float64)
+            z = np.hstack([s * so.l2_normalize_rows(xx[:, off[b] : off[b + 1]]) for b, s in enumerate(sc)])
+            return torch.from_numpy(np.ascontiguousarray(z))
+
+        def topk_fn(z_all, kk, ms, q_row0, nq, n):
+            z = z_all.numpy()[:n]
+            i, s, c = so.topk_fast(z[q_row0 : q_row0 + nq] @ z.T, q_row0, kk, ms)
+            return engine.TopK(torch.from_numpy(i), torch.from_numpy(s), torch.from_numpy(c))
+
+        top, z_all = sharding.sharded_topk(torch.from_numpy(xs), offsets, scales, sh, k, min_sim,
+                                           normalize_fn=normalize_fn, topk_fn=topk_fn)
+        assert z_all.shape[0] == sh.padded_total and top.idx.shape[0] == sh.rows
+        idx = sharding.gather_lists(top.idx, sh)
+        score = sharding.gather_lists(top.score, sh)
+        count = sharding.gather_lists(top.count, sh)
+        if rank == 0:
+            ret["idx"], ret["score"], ret["count"] = idx.numpy(), score.numpy(), count.numpy()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [101, 64])
+def test_sharded_topk_two_ranks_gloo(pkg, n):
+    """world_size 2 over gloo: shard -> normalise -> all-gather -> own rows -> concatenated
+    lists equal the single-process result."""
+    import torch.multiprocessing as mp
+
+    k, min_sim = 7, 0.1
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, n, k, min_sim, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    g, t, p_, ty, la = hybrid_like_blocks(n, seed=11, d_genre=12, d_text=40)
+    x = np.hstack([g, t, p_, ty, la]).astype(np.float32).astype(np.float64)
+    z = np.hstack([np.sqrt(w) * so.l2_normalize_rows(x[:, a:b])
+                   for w, a, b in ((0.4, 0, 12), (0.5, 12, 52), (0.1, 52, 84))])
+    i, s, c = so.topk_fast(z @ z.T, 0, k, min_sim)
+    assert np.array_equal(ret["idx"], i) and np.array_equal(ret["count"], c)
+    assert np.array_equal(ret["score"], s)

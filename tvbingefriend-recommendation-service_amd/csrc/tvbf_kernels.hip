@@ -25,13 +25,15 @@ typedef unsigned long long u64;
 // --------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
 
-static int fail(int code, const char* fmt, ...) {
+// shared with the other translation units of the library
+int tvbf_fail(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
     return code;
 }
+#define fail tvbf_fail
 
 #define HIP_TRY(expr)                                                                    \
     do {                                                                                 \
@@ -142,6 +144,8 @@ struct TopkArgs {
     int row_blocks, splits, col_tiles;
     float min_similarity;
     int exclude_self;
+    float* gram;  // GRAM mode: dense nq x n output, row stride ldo
+    int64_t ldo;
 };
 
 __device__ static inline f32x4 load_chunk(const float* p, bool valid) {
@@ -184,7 +188,11 @@ __device__ static inline void insert_candidates(bool cand, float v, int col, u64
     }
 }
 
-__global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_kernel(TopkArgs a) {
+// GRAM = false: fused top-K (scores stay on chip).  GRAM = true: the same tile
+// engine with the operands swapped (lane = column, registers = query rows) and
+// an epilogue that stores the tile, for callers that need the dense matrix.
+template <bool GRAM>
+__global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* tileQ = reinterpret_cast<float*>(smem);
     float* tileC = tileQ + BM * LDT;
@@ -206,7 +214,7 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_kernel(TopkArgs a
 
     // ---- per-row lists ----
     const float thr0 = a.min_similarity;
-    {
+    if (!GRAM) {
         const u64 s = sentinel_key(thr0);
         for (int i = tid; i < BM * a.k; i += TOPK_THREADS) keys_all[i] = s;
         if (tid < BM) {
@@ -289,10 +297,25 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_kernel(TopkArgs a
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(cf[j][i], qf[i], acc[j], 0, 0, 0);
+                    acc[j] = GRAM ? __builtin_amdgcn_mfma_f32_32x32x2f32(qf[i], cf[j][i], acc[j], 0, 0, 0)
+                                  : __builtin_amdgcn_mfma_f32_32x32x2f32(cf[j][i], qf[i], acc[j], 0, 0, 0);
         }
 
-        if (kb == nkb - 1) {
+        if (GRAM && kb == nkb - 1) {
+            // lane = column (lane & 31) of sub-tile j, registers = query rows of this wave
+            const int64_t col0 = (int64_t)ct * BN;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t c = col0 + 32 * j + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t qr = q0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (qr < a.nq && c < a.n) a.gram[qr * a.ldo + c] = acc[j][r];
+                    acc[j][r] = 0.f;
+                }
+            }
+        }
+        if (!GRAM && kb == nkb - 1) {
             // ------------------------- epilogue -------------------------
             const int64_t col0 = (int64_t)ct * BN;
             const int64_t grow = a.q_row0 + q0 + lrow;  // global index of this lane's query row
@@ -345,6 +368,7 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_kernel(TopkArgs a
         kb = nkbi;
     }
 
+    if (GRAM) return;
     // ---- publish this split's lists ----
     __syncthreads();
     for (int i = tid; i < BM * a.k; i += TOPK_THREADS) {
@@ -545,7 +569,7 @@ int tvbf_cosine_topk_f32(const float* Zq, int64_t nq, int64_t q_row0, const floa
     if (grid > INT32_MAX) return fail(TVBF_E_BAD_ARG, "too many workgroups");
 
     if (p.lds_bytes > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(cosine_topk_kernel),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(cosine_tile_kernel<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
 
     TopkArgs a;
@@ -563,11 +587,44 @@ int tvbf_cosine_topk_f32(const float* Zq, int64_t nq, int64_t q_row0, const floa
     a.col_tiles = p.col_tiles;
     a.min_similarity = min_similarity;
     a.exclude_self = exclude_self;
-    hipLaunchKernelGGL(cosine_topk_kernel, dim3((unsigned)grid), dim3(TOPK_THREADS), p.lds_bytes,
+    a.gram = nullptr;
+    a.ldo = 0;
+    hipLaunchKernelGGL(cosine_tile_kernel<false>, dim3((unsigned)grid), dim3(TOPK_THREADS), p.lds_bytes,
                        (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(topk_finalize_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const u64*>(workspace), nq, k, p.splits, out_idx, out_score, out_count);
+    HIP_TRY(hipGetLastError());
+    return TVBF_OK;
+}
+
+int tvbf_gram_f32(const float* Zq, int64_t nq, const float* Zall, int64_t n, int64_t d, int64_t ld, float* out,
+                  int64_t ldo, void* stream) {
+    if (!Zq || !Zall || !out) return fail(TVBF_E_BAD_ARG, "null pointer argument");
+    if (nq < 0 || n < 1 || d < 1) return fail(TVBF_E_BAD_ARG, "bad nq, n or d");
+    if (n > INT32_MAX - BN || d > INT32_MAX - BK) return fail(TVBF_E_BAD_ARG, "n or d too large");
+    if ((d & 3) || (ld & 3) || ld < d) return fail(TVBF_E_BAD_SHAPE, "d and ld must be multiples of 4, ld >= d");
+    if (((uintptr_t)Zq & 15) || ((uintptr_t)Zall & 15)) return fail(TVBF_E_BAD_SHAPE, "Z must be 16-byte aligned");
+    if (ldo < n) return fail(TVBF_E_BAD_SHAPE, "ldo must be >= n");
+    if (nq == 0) return TVBF_OK;
+    TopkArgs a;
+    memset(&a, 0, sizeof(a));
+    a.zq = Zq;
+    a.zall = Zall;
+    a.nq = nq;
+    a.n = n;
+    a.ld = ld;
+    a.d = (int)d;
+    a.k = 0;
+    a.row_blocks = (int)((nq + BM - 1) / BM);
+    a.col_tiles = (int)((n + BN - 1) / BN);
+    a.splits = a.col_tiles;  // one tile per workgroup
+    a.gram = out;
+    a.ldo = ldo;
+    const int64_t grid = (int64_t)a.row_blocks * a.splits;
+    if (grid > INT32_MAX) return fail(TVBF_E_BAD_ARG, "too many workgroups");
+    hipLaunchKernelGGL(cosine_tile_kernel<true>, dim3((unsigned)grid), dim3(TOPK_THREADS),
+                       (size_t)(BM + BN) * LDT * sizeof(float), (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return TVBF_OK;
 }

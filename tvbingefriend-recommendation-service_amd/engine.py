@@ -152,3 +152,58 @@ def component_scores(z_all: torch.Tensor, offsets, scales, idx: torch.Tensor, *,
                                            idx.data_ptr(), k, out.data_ptr(), _stream_ptr())
     native.check(rc, "tvbf_component_scores_f32")
     return out
+
+
+def gram(z_all: torch.Tensor, *, col0: int = 0, width: int | None = None, q_row0: int = 0,
+         nq: int | None = None, n: int | None = None) -> torch.Tensor:
+    """Dense (nq, n) fp32 matrix z[q rows, cols] @ z[:, cols].T over the column
+    range [col0, col0 + width) of z (default: all columns).  For small n only."""
+    _require_cuda(z_all, "z_all")
+    if z_all.dim() != 2 or not z_all.is_contiguous():
+        raise ValueError("z_all must be a contiguous 2-D tensor")
+    n = z_all.shape[0] if n is None else int(n)
+    nq = n - q_row0 if nq is None else int(nq)
+    ld = z_all.shape[1]
+    width = ld - col0 if width is None else int(width)
+    if col0 % 4 or width % 4 or col0 < 0 or col0 + width > ld:
+        raise ValueError("column ranges must be multiples of 4 floats inside the row")
+    if q_row0 < 0 or q_row0 + nq > z_all.shape[0] or not 1 <= n <= z_all.shape[0]:
+        raise ValueError("rows outside z_all")
+    out = torch.empty((nq, n), dtype=torch.float32, device=z_all.device)
+    lib = native.load()
+    base = z_all.data_ptr() + col0 * 4
+    with torch.cuda.device(z_all.device):
+        rc = lib.tvbf_gram_f32(base + q_row0 * ld * 4, nq, base, n, width, ld, out.data_ptr(), n, _stream_ptr())
+    native.check(rc, "tvbf_gram_f32")
+    return out
+
+
+def weighted_sum3(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, wa: float, wb: float, wc: float):
+    """(wa*a + wb*b) + wc*c in float64 without fused multiply-adds."""
+    for t, name in ((a, "a"), (b, "b"), (c, "c")):
+        _require_cuda(t, name, torch.float64)
+        if not t.is_contiguous() or t.shape != a.shape:
+            raise ValueError("inputs must be contiguous and of one shape")
+    out = torch.empty_like(a)
+    lib = native.load()
+    with torch.cuda.device(a.device):
+        rc = lib.tvbf_weighted_sum3_f64(a.data_ptr(), b.data_ptr(), c.data_ptr(), float(wa), float(wb), float(wc),
+                                        out.data_ptr(), a.numel(), _stream_ptr())
+    native.check(rc, "tvbf_weighted_sum3_f64")
+    return out
+
+
+def upper_tri_stats(m: torch.Tensor) -> torch.Tensor:
+    """{mean, std, min, max, median} of the entries j > i of a square float64 matrix (5 doubles on the GPU)."""
+    _require_cuda(m, "matrix", torch.float64)
+    if m.dim() != 2 or m.shape[0] != m.shape[1] or m.stride(1) != 1:
+        raise ValueError("matrix must be square with contiguous rows")
+    lib = native.load()
+    out = torch.empty(5, dtype=torch.float64, device=m.device)
+    ws_bytes = int(lib.tvbf_stats_workspace_bytes())
+    ws = torch.empty(ws_bytes // 8, dtype=torch.int64, device=m.device)
+    with torch.cuda.device(m.device):
+        rc = lib.tvbf_upper_tri_stats_f64(m.data_ptr(), m.shape[0], m.stride(0), out.data_ptr(), ws.data_ptr(),
+                                          ws_bytes, _stream_ptr())
+    native.check(rc, "tvbf_upper_tri_stats_f64")
+    return out

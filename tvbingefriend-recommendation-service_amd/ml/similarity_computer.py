@@ -1,0 +1,198 @@
+"""Drop-in ``SimilarityComputer`` whose arithmetic runs on the MI355X.
+
+Same constructor, the same six methods, the same argument and return types and
+the same dict keys as the reference class
+(tvbingefriend_recommendation_service/ml/similarity_computer.py:12-190), so
+scripts/compute_similarities.py:107-125 and scripts/populate_database.py:145-147
+can import this class instead.  The dense-matrix methods are meant for the
+sizes the reference can hold in memory; :meth:`topk` is the scalable entry
+point that never forms an n x n matrix.
+
+Every method uploads its inputs, runs HIP kernels through the C ABI and
+downloads the result.  There is no CPU fallback: without a GPU or without the
+built library the methods raise ``NativeLibraryError``.
+"""
+
+from __future__ import annotations
+
+import logging
+from dataclasses import dataclass
+
+import numpy as np
+
+from .. import features as feat
+from .. import native
+
+logger = logging.getLogger(__name__)
+
+
+@dataclass
+class TopKResult:
+    """Neighbours of every show, in row order of the feature matrices.
+
+    idx    (n, k) int32 column index of each neighbour, -1 in unused slots
+    score  (n, k) float32 hybrid similarity, descending
+    count  (n,)   int32 neighbours kept (score >= min_similarity, at most k)
+    comp   (n, k, 3) float64 genre / text / metadata cosine of each kept pair
+    """
+
+    idx: np.ndarray
+    score: np.ndarray
+    count: np.ndarray
+    comp: np.ndarray
+
+
+def _torch_device(device):
+    import torch
+
+    if not torch.cuda.is_available():
+        raise native.NativeLibraryError(
+            "no GPU visible: the similarity path runs on MI355X only (there is no CPU fallback)")
+    return torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+
+
+# noinspection PyMethodMayBeStatic
+class SimilarityComputer:
+    """Compute similarity matrices from feature arrays."""
+
+    def __init__(self, genre_weight: float = 0.4, text_weight: float = 0.5,
+                 metadata_weight: float = 0.1, device=None):
+        self.genre_weight = genre_weight
+        self.text_weight = text_weight
+        self.metadata_weight = metadata_weight
+        self.device = device
+
+    # ---- dense-matrix API (reference: ml/similarity_computer.py:30-130) ----
+
+    def _cosine_matrix(self, features_2d) -> np.ndarray:
+        """cosine_similarity(X) as one normalise launch + one MFMA tile sweep."""
+        import torch
+
+        from .. import engine
+
+        dev = _torch_device(self.device)
+        out_dtype = np.float32 if getattr(features_2d, "dtype", None) == np.float32 else np.float64
+        x, layout = feat.pack_blocks([features_2d], [1.0])
+        z = engine.normalize_blocks(torch.from_numpy(x).to(dev), layout.offsets, [1.0])
+        s = engine.gram(z)
+        return s.cpu().numpy().astype(out_dtype, copy=False)
+
+    def compute_genre_similarity(self, genre_features: np.ndarray) -> np.ndarray:
+        logger.info("Computing genre similarity...")
+        similarity = self._cosine_matrix(genre_features)
+        logger.info(
+            f" Genre similarity: {similarity.shape}, range [{similarity.min():.3f}, {similarity.max():.3f}]"
+        )
+        return similarity
+
+    def compute_text_similarity(self, text_features) -> np.ndarray:
+        logger.info("Computing text similarity...")
+        similarity = self._cosine_matrix(text_features)
+        logger.info(
+            f" Text similarity: {similarity.shape}, range [{similarity.min():.3f}, {similarity.max():.3f}]"
+        )
+        return similarity
+
+    def compute_metadata_similarity(self, platform_features: np.ndarray, type_features: np.ndarray,
+                                    language_features: np.ndarray) -> np.ndarray:
+        logger.info("Computing metadata similarity...")
+        metadata_features = np.hstack([platform_features, type_features, language_features])
+        similarity = self._cosine_matrix(metadata_features)
+        logger.info(
+            f" Metadata similarity: {similarity.shape}, range [{similarity.min():.3f}, {similarity.max():.3f}]"
+        )
+        return similarity
+
+    def compute_hybrid_similarity(self, genre_similarity: np.ndarray, text_similarity: np.ndarray,
+                                  metadata_similarity: np.ndarray) -> np.ndarray:
+        import torch
+
+        from .. import engine
+
+        logger.info("Computing hybrid similarity...")
+        total_weight = self.genre_weight + self.text_weight + self.metadata_weight
+        genre_w = self.genre_weight / total_weight
+        text_w = self.text_weight / total_weight
+        metadata_w = self.metadata_weight / total_weight
+        logger.info(f"  Weights - Genre: {genre_w:.2f}, Text: {text_w:.2f}, Metadata: {metadata_w:.2f}")
+
+        dev = _torch_device(self.device)
+        mats = [np.ascontiguousarray(m, dtype=np.float64) for m in
+                (genre_similarity, text_similarity, metadata_similarity)]
+        if not (mats[0].shape == mats[1].shape == mats[2].shape):
+            raise ValueError("similarity matrices must have one shape")
+        g, t, m = (torch.from_numpy(a).to(dev) for a in mats)
+        hybrid_similarity = engine.weighted_sum3(g, t, m, genre_w, text_w, metadata_w).cpu().numpy()
+        logger.info(
+            f" Hybrid similarity: {hybrid_similarity.shape}, range [{hybrid_similarity.min():.3f}, "
+            f"{hybrid_similarity.max():.3f}]"
+        )
+        return hybrid_similarity
+
+    def compute_all_similarities(self, features: dict) -> dict:
+        logger.info("=" * 60)
+        logger.info("COMPUTING ALL SIMILARITIES")
+        logger.info("=" * 60)
+        genre_similarity = self.compute_genre_similarity(features["genre_features"])
+        text_similarity = self.compute_text_similarity(features["text_features"])
+        metadata_similarity = self.compute_metadata_similarity(
+            features["platform_features"], features["type_features"], features["language_features"]
+        )
+        hybrid_similarity = self.compute_hybrid_similarity(
+            genre_similarity, text_similarity, metadata_similarity
+        )
+        logger.info("=" * 60)
+        logger.info("SIMILARITY COMPUTATION COMPLETE")
+        logger.info("=" * 60)
+        return {
+            "genre_similarity": genre_similarity,
+            "text_similarity": text_similarity,
+            "metadata_similarity": metadata_similarity,
+            "hybrid_similarity": hybrid_similarity,
+        }
+
+    def get_similarity_statistics(self, similarity_matrix: np.ndarray) -> dict:
+        """mean / std / min / max / median over the strict upper triangle
+        (reference: ml/similarity_computer.py:171-190)."""
+        import torch
+
+        from .. import engine
+
+        m = np.ascontiguousarray(similarity_matrix, dtype=np.float64)
+        if m.ndim != 2 or m.shape[0] != m.shape[1]:
+            raise ValueError("input array must be square")  # np.triu_indices_from would need 2-D
+        if m.shape[0] < 2:
+            # NumPy's .min() of the empty upper triangle raises the same way
+            raise ValueError("zero-size array to reduction operation minimum which has no identity")
+        dev = _torch_device(self.device)
+        out = engine.upper_tri_stats(torch.from_numpy(m).to(dev)).cpu().numpy()
+        return {"mean": float(out[0]), "std": float(out[1]), "min": float(out[2]),
+                "max": float(out[3]), "median": float(out[4])}
+
+    # ---- scalable entry point: no n x n matrix ----
+
+    def topk(self, features: dict, k: int = 20, min_similarity: float = 0.1,
+             variant: str = "computer") -> TopKResult:
+        """Top-k hybrid neighbours of every show straight from the feature blocks.
+
+        ``variant`` selects which of the reference's two definitions is followed:
+        "computer" (this class: metadata = cosine of the concatenation, weights
+        divided by their sum) or "populate" (scripts/populate_database.py:184-192:
+        metadata = mean of three cosines, raw weights).
+        """
+        import torch
+
+        from .. import engine
+
+        dev = _torch_device(self.device)
+        x, layout = feat.pack_features(features, self.genre_weight, self.text_weight,
+                                       self.metadata_weight, variant)
+        xd = torch.from_numpy(x).to(dev)
+        scales = layout.scales()
+        z = engine.normalize_blocks(xd, layout.offsets, scales)
+        top = engine.cosine_topk(z, k, min_similarity)
+        cscales = layout.component_scales()
+        zc = z if cscales == scales else engine.normalize_blocks(xd, layout.offsets, cscales)
+        comp = engine.component_scores(zc, layout.offsets, cscales, top.idx)
+        return TopKResult(top.idx.cpu().numpy(), top.score.cpu().numpy(), top.count.cpu().numpy(),
+                          feat.fold_components(comp.cpu().numpy(), layout))

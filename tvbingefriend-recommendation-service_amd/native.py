@@ -15,7 +15,7 @@ from pathlib import Path
 CSRC = Path(__file__).resolve().parent / "csrc"
 INCLUDE = Path(__file__).resolve().parent.parent / "include"
 LIB_PATH = CSRC / "libtvbf.so"
-SOURCES = [CSRC / "tvbf_kernels.hip"]
+SOURCES = [CSRC / "tvbf_kernels.hip", CSRC / "tvbf_stats.hip"]
 
 # Every symbol include/tvbf.h declares.
 SYMBOLS = (
@@ -24,7 +24,11 @@ SYMBOLS = (
     "tvbf_normalize_blocks_f32",
     "tvbf_topk_workspace_bytes",
     "tvbf_cosine_topk_f32",
+    "tvbf_gram_f32",
     "tvbf_component_scores_f32",
+    "tvbf_weighted_sum3_f64",
+    "tvbf_stats_workspace_bytes",
+    "tvbf_upper_tri_stats_f64",
 )
 
 TVBF_MAX_BLOCKS = 8
@@ -96,6 +100,14 @@ def load() -> ctypes.CDLL:
     lib.tvbf_component_scores_f32.restype = c.c_int
     lib.tvbf_component_scores_f32.argtypes = [vp, i64, vp, i64, i64, c.POINTER(i32), c.POINTER(f32), c.c_int,
                                               vp, c.c_int, vp, vp]
+    lib.tvbf_gram_f32.restype = c.c_int
+    lib.tvbf_gram_f32.argtypes = [vp, i64, vp, i64, i64, i64, vp, i64, vp]
+    lib.tvbf_weighted_sum3_f64.restype = c.c_int
+    lib.tvbf_weighted_sum3_f64.argtypes = [vp, vp, vp, c.c_double, c.c_double, c.c_double, vp, i64, vp]
+    lib.tvbf_stats_workspace_bytes.restype = sz
+    lib.tvbf_stats_workspace_bytes.argtypes = []
+    lib.tvbf_upper_tri_stats_f64.restype = c.c_int
+    lib.tvbf_upper_tri_stats_f64.argtypes = [vp, i64, i64, vp, vp, sz, vp]
     _lib = lib
     return lib
 
