@@ -153,6 +153,22 @@ size_t tvbf_stats_workspace_bytes(void);
 int tvbf_upper_tri_stats_f64(const double* M, int64_t n, int64_t ld, double* out5, void* workspace,
                              size_t workspace_bytes, void* stream);
 
+/*
+ * K4 on a dense matrix -- top-k of rows of a float64 score matrix that already
+ * exists in memory: the selection of services/content_based_service.py:206-234
+ * (argsort descending :209, skip self :214-215, stop below min_similarity
+ * :220-221, stop at n :233-234).  Scores are copied, not recomputed, so the
+ * kept (index, score) pairs are exactly the reference's up to the order inside
+ * groups of equal scores (here: column index ascending).
+ *
+ *   H          device, n_rows x n_cols float64, row stride ld; row r is show row0 + r
+ *   out_idx    device, n_rows x k int32 (-1 = unused); out_score n_rows x k float64 (0 = unused)
+ *   out_count  device, n_rows int32
+ */
+int tvbf_dense_rows_topk_f64(const double* H, int64_t n_rows, int64_t n_cols, int64_t ld, int64_t row0,
+                             int k, double min_similarity, int exclude_self, int32_t* out_idx,
+                             double* out_score, int32_t* out_count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

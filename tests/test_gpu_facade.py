@@ -1,0 +1,263 @@
+"""GPU tests of the drop-in Python surface (SimilarityComputer, the two scripts, the service).
+
+The SimilarityComputer tests restate the reference's own unit tests
+(tests/test_ml/test_similarity_computer.py of the reference) against the HIP-backed class.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import load_golden
+from oracle import similarity_oracle as so
+from parity import SCORE_TOL, check_topk_against_golden
+
+pytestmark = pytest.mark.gpu
+
+FEATS = ("genre_features", "text_features", "platform_features", "type_features", "language_features")
+SIMS = ("genre_similarity", "text_similarity", "metadata_similarity", "hybrid_similarity")
+MATRIX_TOL = 1e-6  # the tolerance the reference's own tests use (pytest.approx(abs=1e-6))
+
+
+@pytest.fixture(scope="module")
+def SC(pkg, device):
+    from tvbingefriend_recommendation_service_amd.ml.similarity_computer import SimilarityComputer
+
+    return SimilarityComputer
+
+
+def _golden_features(g):
+    f = {k: g[k] for k in FEATS}
+    f["text_features"] = sp.csr_matrix(f["text_features"])
+    return f
+
+
+# ---- reference tests/test_ml/test_similarity_computer.py, restated ----
+
+def test_init_weights(SC):
+    c = SC()
+    assert (c.genre_weight, c.text_weight, c.metadata_weight) == (0.4, 0.5, 0.1)
+    c = SC(genre_weight=0.3, text_weight=0.6, metadata_weight=0.1)
+    assert (c.genre_weight, c.text_weight, c.metadata_weight) == (0.3, 0.6, 0.1)
+
+
+def test_genre_similarity_basic_identical_disjoint(SC):
+    g = load_golden("conftest_trio")
+    s = SC().compute_genre_similarity(g["genre_features"])
+    assert s.shape == (3, 3) and s.dtype == np.float64
+    assert np.allclose(np.diag(s), 1.0) and np.allclose(s, s.T)
+    assert np.all(s >= -1e-10) and np.all(s <= 1 + 1e-6)
+    s = SC().compute_genre_similarity(np.array([[1, 1, 0], [1, 1, 0]], dtype=float))
+    assert s[0, 1] == pytest.approx(1.0, abs=1e-6) and s[1, 0] == pytest.approx(1.0, abs=1e-6)
+    s = SC().compute_genre_similarity(np.array([[1, 0, 0], [0, 1, 0]], dtype=float))
+    assert s[0, 1] == pytest.approx(0.0, abs=1e-6)
+
+
+def test_text_similarity_dense_and_sparse(SC):
+    s = SC().compute_text_similarity(np.array([[1.0, 0.5, 0.0], [0.5, 1.0, 0.2], [0.0, 0.2, 1.0]]))
+    assert s.shape == (3, 3) and np.allclose(np.diag(s), 1.0) and np.allclose(s, s.T)
+    g = load_golden("conftest_trio")
+    s = SC().compute_text_similarity(sp.csr_matrix(g["text_features"]))
+    assert s.shape == (3, 3) and np.all(s >= -1e-10) and np.all(s <= 1 + 1e-6)
+    s32 = SC().compute_text_similarity(g["text_features"].astype(np.float32))
+    assert s32.dtype == np.float32  # float32 in -> float32 out, like sklearn
+
+
+def test_metadata_similarity(SC):
+    g = load_golden("conftest_trio")
+    s = SC().compute_metadata_similarity(g["platform_features"], g["type_features"], g["language_features"])
+    assert s.shape == (3, 3) and np.allclose(np.diag(s), 1.0) and np.allclose(s, s.T)
+    assert np.abs(s - g["metadata_similarity"]).max() <= MATRIX_TOL
+
+
+def test_hybrid_similarity_known_answers_and_exactness(SC):
+    base = np.array([[1.0, 0.8, 0.2], [0.8, 1.0, 0.3], [0.2, 0.3, 1.0]])
+    h = SC(0.4, 0.5, 0.1).compute_hybrid_similarity(base, base * 0.9, base * 0.8)
+    assert h.shape == (3, 3) and np.allclose(np.diag(h), 0.93, atol=1e-6)
+    h = SC(2.0, 3.0, 1.0).compute_hybrid_similarity(
+        np.array([[1.0, 0.6], [0.6, 1.0]]), np.array([[1.0, 0.8], [0.8, 1.0]]), np.array([[1.0, 0.4], [0.4, 1.0]]))
+    assert h[0, 1] == pytest.approx((2 / 6) * 0.6 + (3 / 6) * 0.8 + (1 / 6) * 0.4, abs=1e-6)
+    h = SC(1.0, 1.0, 1.0).compute_hybrid_similarity(
+        np.array([[1.0, 0.3], [0.3, 1.0]]), np.array([[1.0, 0.6], [0.6, 1.0]]), np.array([[1.0, 0.9], [0.9, 1.0]]))
+    assert h[0, 1] == pytest.approx((0.3 + 0.6 + 0.9) / 3, abs=1e-6)
+    # float64, no fused multiply-add: bit for bit the NumPy expression of the reference
+    rng = np.random.default_rng(1)
+    a, b, c = (rng.random((257, 257)) for _ in range(3))
+    got = SC(0.37, 0.21, 0.11).compute_hybrid_similarity(a, b, c)
+    assert np.array_equal(got, so.SimilarityComputerOracle(0.37, 0.21, 0.11).compute_hybrid_similarity(a, b, c))
+
+
+@pytest.mark.parametrize("name", ["conftest_trio", "edge_frame"])
+def test_compute_all_similarities_matches_reference(SC, name):
+    g = load_golden(name)
+    out = SC().compute_all_similarities(_golden_features(g))
+    assert set(out) == set(SIMS)
+    for k in SIMS:
+        assert out[k].shape == g[k].shape
+        assert np.abs(out[k] - g[k]).max() <= MATRIX_TOL, k
+
+
+def test_statistics(SC):
+    c = SC()
+    st = c.get_similarity_statistics(np.array([[1.0, 0.8, 0.2], [0.8, 1.0, 0.3], [0.2, 0.3, 1.0]]))
+    assert set(st) == {"mean", "std", "min", "max", "median"} and all(isinstance(v, float) for v in st.values())
+    assert st["min"] == 0.2 and st["max"] == 0.8 and st["median"] == 0.3
+    st = c.get_similarity_statistics(np.array([[1.0, 0.5, 0.5], [0.5, 1.0, 0.5], [0.5, 0.5, 1.0]]))
+    assert st["mean"] == pytest.approx(0.5, abs=1e-6) and st["max"] == pytest.approx(0.5, abs=1e-6)
+    m = np.full((4, 4), 0.7)
+    np.fill_diagonal(m, 1.0)
+    st = c.get_similarity_statistics(m)
+    assert all(st[q] == pytest.approx(0.7, abs=1e-6) for q in ("mean", "median", "min", "max"))
+    assert st["std"] == pytest.approx(0.0, abs=1e-6)
+    rng = np.random.default_rng(2)
+    for n in (2, 3, 64, 777):  # even and odd triangle sizes, negatives included
+        m = rng.standard_normal((n, n))
+        got, ref = c.get_similarity_statistics(m), so.SimilarityComputerOracle().get_similarity_statistics(m)
+        assert got["min"] == ref["min"] and got["max"] == ref["max"] and got["median"] == ref["median"], n
+        assert got["mean"] == pytest.approx(ref["mean"], abs=1e-13)
+        assert got["std"] == pytest.approx(ref["std"], rel=1e-12)
+    with pytest.raises(ValueError):
+        c.get_similarity_statistics(np.ones((1, 1)))
+
+
+# ---- scalable path and the scripts ----
+
+def test_gram_and_topk_share_one_arithmetic(pkg, device):
+    """A dense score and the fused path's score of the same pair are the same fp32 number."""
+    import torch
+
+    from tvbingefriend_recommendation_service_amd import engine
+
+    x = np.random.default_rng(3).standard_normal((300, 72)).astype(np.float32)
+    z = engine.normalize_blocks(torch.from_numpy(x).to(device), [0, 72], [1.0])
+    s = engine.gram(z).cpu().numpy()
+    top = engine.cosine_topk(z, 10, -1.0)
+    idx, score = top.idx.cpu().numpy(), top.score.cpu().numpy()
+    assert np.array_equal(np.take_along_axis(s, idx.astype(np.int64), axis=1), score)
+    assert np.array_equal(s, s.T)
+
+
+def _write_feature_dir(tmp_path, g):
+    import pandas as pd
+
+    text = sp.csr_matrix((g["text_data"], g["text_indices"], g["text_indptr"]), shape=tuple(g["text_shape"]))
+    np.save(tmp_path / "genre_features.npy", g["genre_features"])
+    sp.save_npz(tmp_path / "text_features.npz", text)
+    np.save(tmp_path / "platform_features.npy", g["platform_features"])
+    np.save(tmp_path / "type_features.npy", g["type_features"])
+    np.save(tmp_path / "language_features.npy", g["language_features"])
+    pd.DataFrame({"id": g["ids"], "name": [f"s{i}" for i in g["ids"]]}).to_csv(tmp_path / "shows_metadata.csv",
+                                                                                 index=False)
+    return {"genre_features": g["genre_features"], "text_features": text,
+            "platform_features": g["platform_features"], "type_features": g["type_features"],
+            "language_features": g["language_features"]}
+
+
+def test_populate_plumbing_100_shows(pkg, device, tmp_path):
+    """The reference's smallest configuration (100 shows, top-20, min 0.1) end to end:
+    feature files -> compute_and_store_similarities -> sink, against the reference's result."""
+    from tvbingefriend_recommendation_service_amd.scripts import populate_database as pd_amd
+
+    g = load_golden("plumbing_100")
+    feats = _write_feature_dir(tmp_path, g)
+    sink = pd_amd.MemorySimilaritySink()
+    cleared = []
+    stats = pd_amd.compute_and_store_similarities(tmp_path, 0.4, 0.5, 0.1, top_n_per_show=20, min_similarity=0.1,
+                                                  repo=sink, clear_existing=lambda: cleared.append(1))
+    assert cleared == [1] and sink.calls == 1
+    assert stats["top_n_per_show"] == 20 and stats["min_similarity"] == 0.1
+    assert stats["total_records"] == sum(len(v) for v in sink.records.values())
+    ids = g["ids"].tolist()
+    n, k = len(ids), 20
+    idx = np.full((n, k), -1, np.int32)
+    score = np.zeros((n, k))
+    count = np.zeros(n, np.int32)
+    comp = np.zeros((n, k, 3))
+    for r, sid in enumerate(ids):
+        recs = sink.records.get(sid, [])
+        count[r] = len(recs)
+        for s, rec in enumerate(recs):
+            assert set(rec) == {"similar_show_id", "similarity_score", "genre_score", "text_score", "metadata_score"}
+            assert all(isinstance(rec[q], float) for q in rec if q != "similar_show_id")
+            idx[r, s] = ids.index(rec["similar_show_id"])
+            score[r, s] = rec["similarity_score"]
+            comp[r, s] = [rec["genre_score"], rec["text_score"], rec["metadata_score"]]
+    h = g["hybrid_similarity"]
+    hh = h.copy()
+    np.fill_diagonal(hh, -np.inf)
+    srt = -np.sort(-hh, axis=1)[:, : k + 1]
+    check_topk_against_golden(g["idx"], srt, k, idx, score, count, pair_score=lambda r, cols: h[r, cols],
+                              min_similarity=0.1, what="plumbing_100")
+    # component scores against the oracle's per-block cosines of the same pairs
+    blocks, _ = so.hybrid_blocks(feats, 0.4, 0.5, 0.1, variant="populate")
+    bn = [so.l2_normalize_rows(b) for b in blocks]
+    for r in range(n):
+        j = idx[r, : count[r]]
+        ref_g, ref_t = bn[0][r] @ bn[0][j].T, bn[1][r] @ bn[1][j].T
+        ref_m = (bn[2][r] @ bn[2][j].T + bn[3][r] @ bn[3][j].T + bn[4][r] @ bn[4][j].T) / 3
+        assert np.abs(comp[r, : count[r], 0] - ref_g).max(initial=0) <= SCORE_TOL
+        assert np.abs(comp[r, : count[r], 1] - ref_t).max(initial=0) <= SCORE_TOL
+        assert np.abs(comp[r, : count[r], 2] - ref_m).max(initial=0) <= SCORE_TOL
+
+
+def test_compute_similarities_script(pkg, device, tmp_path):
+    from tvbingefriend_recommendation_service_amd.scripts import compute_similarities as cs
+
+    with pytest.raises(FileNotFoundError, match="Run compute_features.py first"):
+        cs.load_features(tmp_path)
+    g = load_golden("plumbing_100")
+    feats = _write_feature_dir(tmp_path, g)
+    loaded = cs.load_features(tmp_path)
+    assert set(loaded) == set(FEATS) and sp.issparse(loaded["text_features"])
+    sims = cs.compute_similarities(loaded, 0.4, 0.5, 0.1)
+    assert np.abs(sims["hybrid_similarity"] - g["hybrid_similarity"]).max() <= MATRIX_TOL
+    cs.save_similarities(sims, tmp_path / "out", save_to_disk=False)
+    assert not (tmp_path / "out").exists()
+    cs.save_similarities(sims, tmp_path / "out", save_to_disk=True)
+    assert sorted(p.name for p in (tmp_path / "out").iterdir()) == sorted(f"{k}.npy" for k in SIMS)
+    with pytest.raises(SystemExit) as e:
+        cs.main(["--input-dir", str(tmp_path), "--genre-weight", "0", "--text-weight", "0", "--metadata-weight", "0"])
+    assert e.value.code == 1
+    with pytest.raises(SystemExit):
+        cs.main(["--input-dir", str(tmp_path / "missing")])
+    out = cs.main(["--input-dir", str(tmp_path)])
+    assert set(out) == set(SIMS)
+
+
+def test_service_matrix_path(pkg, device, tmp_path):
+    """get_recommendations_from_matrix / compute_and_store_all_similarities on stored matrices:
+    float64 scores are copied, so everything but the order inside tie groups is exact."""
+    from tvbingefriend_recommendation_service_amd.scripts.populate_database import MemorySimilaritySink
+    from tvbingefriend_recommendation_service_amd.services.content_based_service import (
+        ContentBasedRecommendationService,
+    )
+
+    g = load_golden("plumbing_100")
+    feats = _write_feature_dir(tmp_path, g)
+    o = so.SimilarityComputerOracle().compute_all_similarities(feats)
+    for k in SIMS[:3]:
+        np.save(tmp_path / f"{k}.npy", o[k])
+    ids = g["ids"].tolist()
+    svc = ContentBasedRecommendationService(tmp_path, 2.0, 3.0, 1.0)
+    hyb = so.service_hybrid(o["genre_similarity"], o["text_similarity"], o["metadata_similarity"], 2.0, 3.0, 1.0)
+    svc._load_similarity_matrices()
+    assert np.array_equal(svc._hybrid_similarity.cpu().numpy(), hyb)
+    for sid in ids[:25]:
+        for n_, ms in ((10, 0.0), (5, 0.3), (50, 0.1), (0, 0.0)):
+            got = svc.get_recommendations_from_matrix(sid, n=n_, min_similarity=ms)
+            ref = so.recommendations_from_matrix(sid, ids, hyb, o["genre_similarity"], o["text_similarity"],
+                                                 o["metadata_similarity"], n=n_, min_similarity=ms,
+                                                 order_fn=so.deterministic_order)
+            assert got == ref, (sid, n_, ms)
+    assert svc.get_recommendations_from_matrix(-5) == []
+    sink = MemorySimilaritySink()
+    stats = svc.compute_and_store_all_similarities(top_n_per_show=20, min_similarity=0.1, repo=sink)
+    assert stats["computed_shows"] == len(sink.records) and stats["top_n_per_show"] == 20
+    for sid in ids:
+        ref = so.recommendations_from_matrix(sid, ids, hyb, o["genre_similarity"], o["text_similarity"],
+                                             o["metadata_similarity"], n=20, min_similarity=0.1,
+                                             order_fn=so.deterministic_order)
+        ref = [{("similar_show_id" if k == "show_id" else k): v for k, v in r.items()} for r in ref]
+        assert sink.records.get(sid, []) == ref

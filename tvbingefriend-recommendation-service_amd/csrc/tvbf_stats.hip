@@ -203,6 +203,63 @@ __global__ void stats_pick_kernel(StatsWs* ws, int shift, double* __restrict__ o
     }
 }
 
+
+// --------------------------------------------------------------------------
+// Top-k of rows of a dense float64 score matrix (the matrix-based service
+// path): k rounds of "best remaining element", one workgroup per row.  The
+// order is score descending, then column ascending; scores are copied, never
+// recomputed, so the result is exact.
+// --------------------------------------------------------------------------
+struct Best {
+    double s;
+    int j;
+};
+__device__ static inline bool better(double s, int j, const Best& b) { return s > b.s || (s == b.s && j < b.j); }
+
+__global__ __launch_bounds__(256) void dense_rows_topk_kernel(const double* __restrict__ h, int64_t n_cols,
+                                                              int64_t ld, int64_t row0, int k, double min_similarity,
+                                                              int exclude_self, int32_t* __restrict__ out_idx,
+                                                              double* __restrict__ out_score,
+                                                              int32_t* __restrict__ out_count) {
+    __shared__ Best sh[4];
+    const int64_t r = blockIdx.x;
+    const double* row = h + r * ld;
+    const int64_t self = exclude_self ? row0 + r : -1;
+    Best last = {INFINITY, -1};
+    int cnt = 0;
+    for (int s = 0; s < k; ++s) {
+        Best b = {-INFINITY, INT32_MAX};
+        for (int64_t j = threadIdx.x; j < n_cols; j += blockDim.x) {
+            if (j == self) continue;
+            const double v = row[j];
+            const bool eligible = v < last.s || (v == last.s && (int)j > last.j);
+            if (eligible && better(v, (int)j, b)) b = {v, (int)j};
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            Best t = {__shfl_xor(b.s, o, 64), __shfl_xor(b.j, o, 64)};
+            if (better(t.s, t.j, b)) b = t;
+        }
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = b;
+        __syncthreads();
+        b = sh[0];
+        for (int w = 1; w < 4; ++w)
+            if (better(sh[w].s, sh[w].j, b)) b = sh[w];
+        if (b.j == INT32_MAX || !(b.s >= min_similarity)) break;  // nothing left / below the threshold
+        if (threadIdx.x == 0) {
+            out_idx[r * k + s] = b.j;
+            out_score[r * k + s] = b.s;
+        }
+        last = b;
+        ++cnt;
+    }
+    for (int s = cnt + threadIdx.x; s < k; s += blockDim.x) {
+        out_idx[r * k + s] = -1;
+        out_score[r * k + s] = 0.0;
+    }
+    if (threadIdx.x == 0) out_count[r] = cnt;
+}
+
 extern "C" {
 
 int tvbf_weighted_sum3_f64(const double* a, const double* b, const double* c, double wa, double wb, double wc,
@@ -238,6 +295,22 @@ int tvbf_upper_tri_stats_f64(const double* M, int64_t n, int64_t ld, double* out
         hipLaunchKernelGGL(stats_hist_kernel, dim3(ST_BLOCKS), dim3(ST_THREADS), 0, s, M, n, ld, ws, shift);
         hipLaunchKernelGGL(stats_pick_kernel, dim3(1), dim3(64), 0, s, ws, shift, out5);
     }
+    HIP_TRY(hipGetLastError());
+    return TVBF_OK;
+}
+
+int tvbf_dense_rows_topk_f64(const double* H, int64_t n_rows, int64_t n_cols, int64_t ld, int64_t row0, int k,
+                             double min_similarity, int exclude_self, int32_t* out_idx, double* out_score,
+                             int32_t* out_count, void* stream) {
+    if (!H || !out_idx || !out_score || !out_count) return tvbf_fail(TVBF_E_BAD_ARG, "null pointer argument");
+    if (n_rows < 0 || n_cols < 1 || n_cols > INT32_MAX - 1 || n_rows > INT32_MAX)
+        return tvbf_fail(TVBF_E_BAD_ARG, "bad n_rows or n_cols");
+    if (k < 1) return tvbf_fail(TVBF_E_BAD_ARG, "k must be >= 1");
+    if (ld < n_cols) return tvbf_fail(TVBF_E_BAD_SHAPE, "ld must be >= n_cols");
+    if (min_similarity != min_similarity) return tvbf_fail(TVBF_E_BAD_ARG, "min_similarity is NaN");
+    if (n_rows == 0) return TVBF_OK;
+    hipLaunchKernelGGL(dense_rows_topk_kernel, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, H, n_cols,
+                       ld, row0, k, min_similarity, exclude_self, out_idx, out_score, out_count);
     HIP_TRY(hipGetLastError());
     return TVBF_OK;
 }

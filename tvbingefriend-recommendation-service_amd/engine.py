@@ -207,3 +207,29 @@ def upper_tri_stats(m: torch.Tensor) -> torch.Tensor:
                                           ws_bytes, _stream_ptr())
     native.check(rc, "tvbf_upper_tri_stats_f64")
     return out
+
+
+def dense_rows_topk(h: torch.Tensor, k: int, min_similarity: float, *, row0: int = 0, rows: int | None = None,
+                    exclude_self: bool = True):
+    """Top-k of rows ``row0 .. row0+rows`` of a dense float64 score matrix (n, n) on the GPU.
+    Returns (idx int32 (rows,k), score float64 (rows,k), count int32 (rows,))."""
+    _require_cuda(h, "matrix", torch.float64)
+    if h.dim() != 2 or h.stride(1) != 1:
+        raise ValueError("matrix must be 2-D with contiguous rows")
+    n_all, n_cols = h.shape
+    rows = n_all - row0 if rows is None else int(rows)
+    if row0 < 0 or rows < 0 or row0 + rows > n_all:
+        raise ValueError("rows outside the matrix")
+    if k < 1:
+        raise ValueError("k must be >= 1")
+    dev = h.device
+    idx = torch.empty((rows, k), dtype=torch.int32, device=dev)
+    score = torch.empty((rows, k), dtype=torch.float64, device=dev)
+    count = torch.empty((rows,), dtype=torch.int32, device=dev)
+    lib = native.load()
+    with torch.cuda.device(dev):
+        rc = lib.tvbf_dense_rows_topk_f64(h.data_ptr() + row0 * h.stride(0) * 8, rows, n_cols, h.stride(0), row0, k,
+                                          float(min_similarity), 1 if exclude_self else 0, idx.data_ptr(),
+                                          score.data_ptr(), count.data_ptr(), _stream_ptr())
+    native.check(rc, "tvbf_dense_rows_topk_f64")
+    return idx, score, count

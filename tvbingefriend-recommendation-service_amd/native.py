@@ -29,6 +29,7 @@ SYMBOLS = (
     "tvbf_weighted_sum3_f64",
     "tvbf_stats_workspace_bytes",
     "tvbf_upper_tri_stats_f64",
+    "tvbf_dense_rows_topk_f64",
 )
 
 TVBF_MAX_BLOCKS = 8
@@ -108,6 +109,8 @@ def load() -> ctypes.CDLL:
     lib.tvbf_stats_workspace_bytes.argtypes = []
     lib.tvbf_upper_tri_stats_f64.restype = c.c_int
     lib.tvbf_upper_tri_stats_f64.argtypes = [vp, i64, i64, vp, vp, sz, vp]
+    lib.tvbf_dense_rows_topk_f64.restype = c.c_int
+    lib.tvbf_dense_rows_topk_f64.argtypes = [vp, i64, i64, i64, i64, c.c_int, c.c_double, c.c_int, vp, vp, vp, vp]
     _lib = lib
     return lib
 

@@ -1,0 +1,152 @@
+"""MI355X counterpart of ``compute_and_store_similarities`` of the reference's
+scripts/populate_database.py:85-259 -- the production top-K path.
+
+The reference walks the shows one at a time: five one-row cosine similarities,
+the weighted sum, a full argsort and a Python loop per show (:170-218).  Here
+the whole catalogue goes through three kernel launches (normalise, fused
+similarity + top-K, per-block scores) and only the K kept neighbours per show
+come back to the host, where they are turned into the same
+``{show_id: [record, ...]}`` dicts and handed to the same sink in the same
+batches of 5000 shows (:166, :224-234).
+"""
+
+from __future__ import annotations
+
+import logging
+from pathlib import Path
+
+import numpy as np
+
+from .. import features as feat
+from ..ml.similarity_computer import SimilarityComputer, TopKResult
+from .compute_similarities import load_features
+
+logger = logging.getLogger(__name__)
+
+FLUSH_EVERY = 5000  # shows per bulk_store_all_similarities call (populate_database.py:166)
+
+
+def neighbour_records(result: TopKResult, show_ids, start: int, stop: int) -> dict:
+    """Rows [start, stop) of a top-K result as the reference's record dicts
+    (populate_database.py:210-221): Python ints/floats, shows without neighbours omitted."""
+    out = {}
+    idx, score, count, comp = result.idx, result.score, result.count, result.comp
+    for r in range(start, stop):
+        c = int(count[r])
+        if c == 0:
+            continue
+        out[show_ids[r]] = [
+            {
+                "similar_show_id": show_ids[int(idx[r, s])],
+                "similarity_score": float(score[r, s]),
+                "genre_score": float(comp[r, s, 0]),
+                "text_score": float(comp[r, s, 1]),
+                "metadata_score": float(comp[r, s, 2]),
+            }
+            for s in range(c)
+        ]
+    return out
+
+
+def compute_top_neighbours(features: dict, genre_weight: float = 0.4, text_weight: float = 0.5,
+                           metadata_weight: float = 0.1, top_n_per_show: int = 20,
+                           min_similarity: float = 0.1, device=None) -> TopKResult:
+    """Columnar result of the production path (metadata = mean of three cosines,
+    raw weights: populate_database.py:184-192) for array-native sinks."""
+    sc = SimilarityComputer(genre_weight=genre_weight, text_weight=text_weight,
+                            metadata_weight=metadata_weight, device=device)
+    return sc.topk(features, k=top_n_per_show, min_similarity=min_similarity, variant="populate")
+
+
+def compute_and_store_similarities(input_dir: Path, genre_weight: float = 0.4, text_weight: float = 0.5,
+                                   metadata_weight: float = 0.1, top_n_per_show: int = 20,
+                                   min_similarity: float = 0.1, repo=None, clear_existing=None) -> dict:
+    """Compute the top-N neighbours of every show and store them.
+
+    ``repo`` is the sink: any object with ``bulk_store_all_similarities(dict,
+    clear_existing=False) -> int`` and ``get_similarity_stats() -> dict`` (the
+    reference's ``SimilarityRepository``, repos/similarity_repository.py:72,243).
+    ``clear_existing`` is called once before the first write (the reference
+    deletes all rows of show_similarities there, populate_database.py:160-161).
+    When ``repo`` is None the reference's own repository and session are used,
+    which needs the reference package and its database to be importable.
+    """
+    import pandas as pd
+
+    input_dir = Path(input_dir)
+    logger.info("COMPUTING AND STORING SIMILARITIES")
+    logger.info(f"Genre weight: {genre_weight}  Text weight: {text_weight}  Metadata weight: {metadata_weight}")
+    logger.info(f"Top N per show: {top_n_per_show}  Min similarity: {min_similarity}")
+
+    features = load_features(input_dir)
+    show_ids = pd.read_csv(input_dir / "shows_metadata.csv")["id"].tolist()
+    n = len(show_ids)
+    if features["genre_features"].shape[0] != n:
+        raise ValueError("shows_metadata.csv and the feature files disagree on the number of shows")
+
+    db = None
+    if repo is None:  # drop-in inside the reference's own process
+        from tvbingefriend_recommendation_service.models import ShowSimilarity
+        from tvbingefriend_recommendation_service.models.database import SessionLocal
+        from tvbingefriend_recommendation_service.repos import SimilarityRepository
+
+        db = SessionLocal()
+        repo = SimilarityRepository(db)
+        if clear_existing is None:
+            def clear_existing():
+                db.query(ShowSimilarity).delete()
+                db.commit()
+    try:
+        if clear_existing is not None:
+            logger.info("Clearing existing similarities from database...")
+            clear_existing()
+
+        result = compute_top_neighbours(features, genre_weight, text_weight, metadata_weight,
+                                        top_n_per_show, min_similarity)
+        total_records_stored = 0
+        for start in range(0, n, FLUSH_EVERY):
+            stop = min(n, start + FLUSH_EVERY)
+            batch = neighbour_records(result, show_ids, start, stop)
+            if batch:
+                total_records_stored += repo.bulk_store_all_similarities(batch, clear_existing=False)
+            logger.info(f"  Processed {stop}/{n} shows... (stored {total_records_stored} similarity records)")
+        logger.info(f"✓ Stored {total_records_stored} total similarity records")
+
+        stats = repo.get_similarity_stats()
+        stats["total_records"] = total_records_stored
+        stats["top_n_per_show"] = top_n_per_show
+        stats["min_similarity"] = min_similarity
+        return stats
+    finally:
+        if db is not None:
+            db.close()
+
+
+class MemorySimilaritySink:
+    """In-memory stand-in for ``SimilarityRepository`` with the two methods the
+    path calls; used by the plumbing test and handy for dry runs."""
+
+    def __init__(self):
+        self.records: dict = {}
+        self.calls = 0
+
+    def clear(self):
+        self.records.clear()
+
+    def bulk_store_all_similarities(self, all_similarities: dict, batch_size: int = 1000,
+                                    clear_existing: bool = True) -> int:
+        if clear_existing:
+            self.records.clear()
+        self.calls += 1
+        total = 0
+        for show_id, items in all_similarities.items():
+            self.records[show_id] = list(items)
+            total += len(items)
+        return total
+
+    def get_similarity_stats(self) -> dict:
+        total = sum(len(v) for v in self.records.values())
+        shows = len(self.records)
+        # same keys as repos/similarity_repository.py:258-263 of the reference
+        return {"total_records": total, "unique_shows": shows,
+                "avg_similarities_per_show": (total / shows) if shows else 0, "last_computed": None}

@@ -1,0 +1,181 @@
+"""MI355X counterpart of the matrix-based methods of the reference's
+``ContentBasedRecommendationService`` (services/content_based_service.py):
+``_load_similarity_matrices`` (:113-140), ``_load_show_mappings`` (:142-159),
+``get_recommendations_from_matrix`` (:161-236) and
+``compute_and_store_all_similarities`` (:262-338).
+
+The three dense matrices are loaded from disk as in the reference; the hybrid
+matrix is formed on the GPU with the same float64 arithmetic (bit for bit),
+stays in HBM, and rows are ranked by a selection kernel instead of a full
+argsort per show.  Database access, blob download and metadata sync are the
+reference's own and are not re-implemented: the sink is injected.
+"""
+
+from __future__ import annotations
+
+import logging
+from pathlib import Path
+
+import numpy as np
+
+from .. import native
+
+logger = logging.getLogger(__name__)
+
+
+class ContentBasedRecommendationService:
+    """Serve recommendations from pre-computed similarity matrices."""
+
+    def __init__(self, processed_data_dir: Path | None = None, genre_weight: float = 0.4,
+                 text_weight: float = 0.5, metadata_weight: float = 0.1, use_blob: bool | None = None,
+                 blob_prefix: str = "processed", device=None, repo_factory=None):
+        if processed_data_dir is None:
+            processed_data_dir = Path.cwd() / "data" / "processed"
+        if use_blob:
+            raise NotImplementedError(
+                "blob download belongs to the reference's storage layer; download the files first "
+                "and pass processed_data_dir")
+        self.processed_data_dir = Path(processed_data_dir)
+        self.genre_weight = genre_weight
+        self.text_weight = text_weight
+        self.metadata_weight = metadata_weight
+        self.use_blob = False
+        self.blob_prefix = blob_prefix
+        self.device = device
+        self._repo_factory = repo_factory
+
+        self._genre_similarity = None      # torch float64 (n, n) on the GPU
+        self._text_similarity = None
+        self._metadata_similarity = None
+        self._hybrid_similarity = None
+        self._show_id_to_index: dict | None = None
+        self._index_to_show_id: dict | None = None
+        logger.info("Initialized ContentBasedRecommendationService")
+        logger.info(f"Weights - Genre: {genre_weight}, Text: {text_weight}, Metadata: {metadata_weight}")
+
+    def _get_data_dir(self) -> Path:
+        return self.processed_data_dir
+
+    def _device(self):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise native.NativeLibraryError(
+                "no GPU visible: the similarity path runs on MI355X only (there is no CPU fallback)")
+        return torch.device(self.device if self.device is not None else f"cuda:{torch.cuda.current_device()}")
+
+    def _load_similarity_matrices(self):
+        """np.load the three matrices, form the hybrid with normalised weights on the GPU."""
+        if self._hybrid_similarity is not None:
+            return
+        import torch
+
+        from .. import engine
+
+        logger.info("Loading similarity matrices...")
+        data_dir = self._get_data_dir()
+        dev = self._device()
+        mats = []
+        for name in ("genre_similarity", "text_similarity", "metadata_similarity"):
+            m = np.ascontiguousarray(np.load(data_dir / f"{name}.npy"), dtype=np.float64)
+            mats.append(torch.from_numpy(m).to(dev))
+        self._genre_similarity, self._text_similarity, self._metadata_similarity = mats
+        total_weight = self.genre_weight + self.text_weight + self.metadata_weight
+        self._hybrid_similarity = engine.weighted_sum3(
+            mats[0], mats[1], mats[2], self.genre_weight / total_weight,
+            self.text_weight / total_weight, self.metadata_weight / total_weight)
+        logger.info(f"✓ Loaded similarity matrices: {tuple(self._hybrid_similarity.shape)}")
+
+    def _load_show_mappings(self):
+        """Row order of shows_metadata.csv["id"] defines the matrix index of every show."""
+        if self._show_id_to_index is not None:
+            return
+        import pandas as pd
+
+        metadata_df = pd.read_csv(self._get_data_dir() / "shows_metadata.csv")
+        self._show_id_to_index = {show_id: idx for idx, show_id in enumerate(metadata_df["id"])}
+        self._index_to_show_id = {idx: show_id for show_id, idx in self._show_id_to_index.items()}
+        logger.info(f"✓ Loaded mappings for {len(self._show_id_to_index)} shows")
+
+    def _rank_rows(self, row0: int, rows: int, n: int, min_similarity: float):
+        """Selection kernel + gathers of the three component matrices for rows [row0, row0+rows)."""
+        import torch
+
+        from .. import engine
+
+        idx, score, count = engine.dense_rows_topk(self._hybrid_similarity, n, min_similarity,
+                                                   row0=row0, rows=rows)
+        safe = idx.clamp_min(0).long()
+        sl = slice(row0, row0 + rows)
+        comps = [torch.gather(m[sl], 1, safe) for m in
+                 (self._genre_similarity, self._text_similarity, self._metadata_similarity)]
+        return (idx.cpu().numpy(), score.cpu().numpy(), count.cpu().numpy(),
+                [c.cpu().numpy() for c in comps])
+
+    def get_recommendations_from_matrix(self, show_id: int, n: int = 10,
+                                        min_similarity: float = 0.0) -> list:
+        """Top-n neighbours of one show straight from the matrices (no database)."""
+        self._load_similarity_matrices()
+        self._load_show_mappings()
+        if show_id not in self._show_id_to_index:
+            logger.warning(f"Show ID {show_id} not found in similarity matrix")
+            return []
+        if n < 1:
+            # the reference appends the best neighbour before it tests the length (:223-234)
+            n_eff = 1
+        else:
+            n_eff = n
+        show_idx = self._show_id_to_index[show_id]
+        idx, score, count, comps = self._rank_rows(show_idx, 1, n_eff, min_similarity)
+        return self._records(idx[0], score[0], int(count[0]), [c[0] for c in comps], "show_id")
+
+    def _records(self, idx, score, count, comps, id_key):
+        return [
+            {
+                id_key: self._index_to_show_id[int(idx[s])],
+                "similarity_score": float(score[s]),
+                "genre_score": float(comps[0][s]),
+                "text_score": float(comps[1][s]),
+                "metadata_score": float(comps[2][s]),
+            }
+            for s in range(count)
+        ]
+
+    def compute_and_store_all_similarities(self, top_n_per_show: int = 20, min_similarity: float = 0.1,
+                                           repo=None) -> dict:
+        """Rank every row in one launch and store the lists through ``repo``
+        (``bulk_store_all_similarities`` / ``get_similarity_stats``; default: the factory given
+        to the constructor, else the reference's SimilarityRepository on its own session)."""
+        self._load_similarity_matrices()
+        self._load_show_mappings()
+        total_shows = len(self._show_id_to_index)
+        logger.info(f"Computing similarities for {total_shows} shows...")
+        idx, score, count, comps = self._rank_rows(0, total_shows, max(top_n_per_show, 1), min_similarity)
+        all_similarities = {}
+        for r in range(total_shows):
+            c = int(count[r])
+            if c:
+                all_similarities[self._index_to_show_id[r]] = self._records(
+                    idx[r], score[r], c, [m[r] for m in comps], "similar_show_id")
+        logger.info(f"✓ Computed similarities for {len(all_similarities)} shows")
+
+        db = None
+        if repo is None and self._repo_factory is not None:
+            repo = self._repo_factory()
+        if repo is None:
+            from tvbingefriend_recommendation_service.models.database import SessionLocal
+            from tvbingefriend_recommendation_service.repos import SimilarityRepository
+
+            db = SessionLocal()
+            repo = SimilarityRepository(db)
+        try:
+            total_records = repo.bulk_store_all_similarities(all_similarities)
+            stats = repo.get_similarity_stats()
+            stats["computed_shows"] = len(all_similarities)
+            stats["top_n_per_show"] = top_n_per_show
+            stats["min_similarity"] = min_similarity
+            logger.info(f"Total records stored: {total_records}")
+            return stats
+        finally:
+            if db is not None:
+                db.close()
