@@ -11,6 +11,9 @@
 
 typedef unsigned long long u64;
 
+// float64 results here are compared bit for bit with NumPy: never fuse a*b+c
+#pragma clang fp contract(off)
+
 int tvbf_fail(int code, const char* fmt, ...);  // tvbf_kernels.hip
 
 #define HIP_TRY(expr)                                                                         \
@@ -30,8 +33,8 @@ __global__ __launch_bounds__(256) void weighted_sum3_kernel(const double* __rest
                                                             double wc, double* __restrict__ out, int64_t count) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
-        const double t = __dadd_rn(__dmul_rn(wa, a[i]), __dmul_rn(wb, b[i]));
-        out[i] = __dadd_rn(t, __dmul_rn(wc, c[i]));
+        const double t = wa * a[i] + wb * b[i];  // contraction is off: three products, two sums
+        out[i] = t + wc * c[i];
     }
 }
 
