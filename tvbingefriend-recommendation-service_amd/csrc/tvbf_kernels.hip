@@ -140,7 +140,7 @@ struct TopkArgs {
     const float* zall;
     u64* partial;  // [splits][nq][k]
     int64_t nq, n, q_row0, ld;
-    int d, k;
+    int d, k, cap;
     int row_blocks, splits, col_tiles;
     float min_similarity;
     int exclude_self;
@@ -154,38 +154,39 @@ __device__ static inline f32x4 load_chunk(const float* p, bool valid) {
     return v;
 }
 
-// Insert the candidates of the active lanes (`cand`) into the unsorted K-entry
-// lists of their query rows.  Lanes l and l+32 share a row, so the two halves
-// of the wave take turns.  `keys` points at this lane's row list, `mink`/`minp`
-// at the row's smallest key and its slot.
-__device__ static inline void insert_candidates(bool cand, float v, int col, u64* keys, u64* mink,
-                                                int* minp, int k, int half) {
-    const u64 key = make_key(v, col);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        if (cand && half == h) {
-            const u64 mk = *mink;
-            if (key > mk) {
-                keys[*minp] = key;
-                u64 nm = keys[0];
-                int np = 0;
+// Per-row candidate buffers.  Every query row owns `cap` = K + slack 64-bit keys
+// in LDS, an entry count and the key of its K-th best neighbour as of the last
+// compaction (the acceptance threshold; before the first compaction it is the
+// min_similarity sentinel).  Accepting a candidate is one LDS atomic and one
+// store; only when a buffer is full does the wave stop to compact that row.
+//
+// compact_row: all 64 lanes rank the row's keys by counting (keys are unique:
+// one per column), the K best are rewritten in descending order at the front,
+// the K-th becomes the new threshold.  Wave-uniform call; LDS is in-order
+// within a wave, so reads of the loop complete before the writes that follow.
+__device__ static inline void compact_row(u64* buf, unsigned* cnt, u64* mkey, int k, int cap, int lane) {
+    int valid = (int)*cnt;
+    if (valid > cap) valid = cap;
+    valid = __builtin_amdgcn_readfirstlane(valid);
+    const bool has0 = lane < valid, has1 = lane + 64 < valid;
+    const u64 my0 = has0 ? buf[lane] : 0ull;
+    const u64 my1 = has1 ? buf[lane + 64] : 0ull;
+    int r0 = 0, r1 = 0;
 #pragma nounroll
-                for (int i = 1; i < k; ++i) {
-                    const u64 x = keys[i];
-                    if (x < nm) {
-                        nm = x;
-                        np = i;
-                    }
-                }
-                *mink = nm;
-                *minp = np;
-            }
-        }
-        // the other half must see these LDS writes: same wave, in-order LDS,
-        // only the compiler has to be kept from reordering
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+    for (int i = 0; i < valid; ++i) {
+        const u64 o = buf[i];  // same address in every lane: LDS broadcast
+        r0 += o > my0 ? 1 : 0;
+        r1 += o > my1 ? 1 : 0;
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (has0 && r0 < k) buf[r0] = my0;
+    if (has1 && r1 < k) buf[r1] = my1;
+    if (has0 && r0 == k - 1) *mkey = my0;
+    if (has1 && r1 == k - 1) *mkey = my1;
+    if (lane == 0) *cnt = (unsigned)(valid < k ? valid : k);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
 // GRAM = false: fused top-K (scores stay on chip).  GRAM = true: the same tile
@@ -196,9 +197,9 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* tileQ = reinterpret_cast<float*>(smem);
     float* tileC = tileQ + BM * LDT;
-    u64* keys_all = reinterpret_cast<u64*>(tileC + BN * LDT);
-    u64* mink_all = keys_all + (size_t)BM * a.k;
-    int* minp_all = reinterpret_cast<int*>(mink_all + BM);
+    u64* buf_all = reinterpret_cast<u64*>(tileC + BN * LDT);  // [BM][cap]
+    u64* mkey_all = buf_all + (size_t)BM * a.cap;               // [BM]
+    unsigned* cnt_all = reinterpret_cast<unsigned*>(mkey_all + BM);  // [BM]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -212,20 +213,16 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
     const int tile_end = (int)(((int64_t)a.col_tiles * (split + 1)) / a.splits);
     const int64_t q0 = (int64_t)rb * BM;  // first query row (local to zq)
 
-    // ---- per-row lists ----
-    const float thr0 = a.min_similarity;
-    if (!GRAM) {
-        const u64 s = sentinel_key(thr0);
-        for (int i = tid; i < BM * a.k; i += TOPK_THREADS) keys_all[i] = s;
-        if (tid < BM) {
-            mink_all[tid] = s;
-            minp_all[tid] = 0;
-        }
+    // ---- per-row candidate buffers (rows of wave w are touched by wave w only) ----
+    if (!GRAM && tid < BM) {
+        mkey_all[tid] = sentinel_key(a.min_similarity);
+        cnt_all[tid] = 0u;
     }
-    u64* my_keys = keys_all + (size_t)lrow * a.k;
-    u64* my_mink = mink_all + lrow;
-    int* my_minp = minp_all + lrow;
-    float thr = thr0;
+    u64* my_buf = buf_all + (size_t)lrow * a.cap;
+    u64* my_mkey = mkey_all + lrow;
+    unsigned* my_cnt = cnt_all + lrow;
+    u64 mkey = sentinel_key(a.min_similarity);  // register copy of the row's threshold key
+    float thr = a.min_similarity;               // its score part
 
     // ---- staging geometry: thread -> (row r + 32 i, 16-byte chunk c) ----
     const int sc = tid & 7;
@@ -350,11 +347,33 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
 #pragma nounroll
                     for (int r = 0; r < 16; ++r) {
                         const float v = scratch[r * 64 + lane];
-                        const bool cand = v >= thr;
-                        if (__any(cand)) {
-                            const int c = (int)col0 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * half;
-                            insert_candidates(cand, v, c, my_keys, my_mink, my_minp, a.k, half);
-                            thr = ordered_to_f32((uint32_t)(*my_mink >> 32));
+                        const int c = (int)col0 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        const u64 key = make_key(v, c);
+                        bool cand = v >= thr && key > mkey;
+                        while (__any(cand)) {
+                            if (cand) {
+                                const unsigned pos = atomicAdd(my_cnt, 1u);
+                                if (pos < (unsigned)a.cap) {
+                                    my_buf[pos] = key;
+                                    cand = false;
+                                }
+                            }
+                            u64 full = __ballot(cand);
+                            if (full) {
+                                // some buffers are full: compact those rows, then retry what is left
+                                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                                __builtin_amdgcn_wave_barrier();
+                                while (full) {
+                                    const int l = (int)__builtin_ctzll(full) & 31;
+                                    const int row = wave * 32 + l;
+                                    compact_row(buf_all + (size_t)row * a.cap, cnt_all + row, mkey_all + row, a.k,
+                                                a.cap, lane);
+                                    full &= ~((1ull << l) | (1ull << (l + 32)));
+                                }
+                                mkey = *my_mkey;
+                                thr = ordered_to_f32((uint32_t)(mkey >> 32));
+                                cand = cand && key > mkey;
+                            }
                         }
                     }
                 }
@@ -369,12 +388,19 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
     }
 
     if (GRAM) return;
-    // ---- publish this split's lists ----
-    __syncthreads();
-    for (int i = tid; i < BM * a.k; i += TOPK_THREADS) {
-        const int r = i / a.k;
-        const int64_t qr = q0 + r;
-        if (qr < a.nq) a.partial[((int64_t)split * a.nq + qr) * a.k + (i - r * a.k)] = keys_all[i];
+    // ---- final compaction and publication of this split's lists (per wave) ----
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const u64 empty = sentinel_key(a.min_similarity);
+#pragma nounroll
+    for (int l = 0; l < 32; ++l) {
+        const int row = wave * 32 + l;
+        const int64_t qr = q0 + row;
+        if (qr >= a.nq) break;
+        compact_row(buf_all + (size_t)row * a.cap, cnt_all + row, mkey_all + row, a.k, a.cap, lane);
+        const int have = (int)cnt_all[row];
+        u64* dst = a.partial + ((int64_t)split * a.nq + qr) * a.k;
+        for (int i = lane; i < a.k; i += 64) dst[i] = i < have ? buf_all[(size_t)row * a.cap + i] : empty;
     }
 }
 
@@ -469,8 +495,17 @@ static int device_cus() {
     return cus;
 }
 
+// Buffer entries per row: K plus slack so that compactions are amortised over
+// several accepted candidates.  K <= 30 keeps two workgroups per CU (<= 80 KB
+// each); K <= 52 uses 64 entries (one key per lane in a compaction).
+static int topk_cap(int k) {
+    if (k <= 30) return k + 12;
+    if (k <= 52) return 64;
+    return k + 12;
+}
+
 static size_t topk_lds_bytes(int k) {
-    return (size_t)(BM + BN) * LDT * sizeof(float) + (size_t)BM * k * 8 + (size_t)BM * 8 + (size_t)BM * 4;
+    return (size_t)(BM + BN) * LDT * sizeof(float) + (size_t)BM * topk_cap(k) * 8 + (size_t)BM * 8 + (size_t)BM * 4;
 }
 
 // Column splits trade tail balance (more, shorter workgroups) against repeated
@@ -582,6 +617,7 @@ int tvbf_cosine_topk_f32(const float* Zq, int64_t nq, int64_t q_row0, const floa
     a.ld = ld;
     a.d = (int)d;
     a.k = k;
+    a.cap = topk_cap(k);
     a.row_blocks = p.row_blocks;
     a.splits = p.splits;
     a.col_tiles = p.col_tiles;
