@@ -11,6 +11,7 @@
 #include <stdint.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <float.h>
 
@@ -139,6 +140,7 @@ struct TopkArgs {
     const float* zq;
     const float* zall;
     u64* partial;  // [splits][nq][k]
+    unsigned* bound;  // [nq] best known lower bound of every row's K-th score (ordered bits)
     int64_t nq, n, q_row0, ld;
     int d, k, cap;
     int row_blocks, splits, col_tiles;
@@ -150,7 +152,12 @@ struct TopkArgs {
 
 __device__ static inline f32x4 load_chunk(const float* p, bool valid) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#ifdef TVBF_DIAG_NO_LOADS  // timing-only build: no global traffic
+    asm volatile("" ::"v"(p));
+    v[0] = valid ? 1.f : 0.f;
+#else
     if (valid) v = *reinterpret_cast<const f32x4*>(p);
+#endif
     return v;
 }
 
@@ -164,7 +171,15 @@ __device__ static inline f32x4 load_chunk(const float* p, bool valid) {
 // one per column), the K best are rewritten in descending order at the front,
 // the K-th becomes the new threshold.  Wave-uniform call; LDS is in-order
 // within a wave, so reads of the loop complete before the writes that follow.
-__device__ static inline void compact_row(u64* buf, unsigned* cnt, u64* mkey, int k, int cap, int lane) {
+//
+// The K-th score is also published (atomic max) to the row's global bound,
+// which the workgroups of the other column splits of the same row read: the
+// K-th best of ANY subset of columns is a lower bound of the row's final K-th
+// best, so a score strictly below it can be dropped at once.  The bound is a
+// hint only: stale or missing values change how much work is skipped, never
+// which neighbours are kept.
+__device__ static inline void compact_row(u64* buf, unsigned* cnt, u64* mkey, int k, int cap, int lane,
+                                          unsigned* gbound) {
     int valid = (int)*cnt;
     if (valid > cap) valid = cap;
     valid = __builtin_amdgcn_readfirstlane(valid);
@@ -182,8 +197,14 @@ __device__ static inline void compact_row(u64* buf, unsigned* cnt, u64* mkey, in
     __builtin_amdgcn_wave_barrier();
     if (has0 && r0 < k) buf[r0] = my0;
     if (has1 && r1 < k) buf[r1] = my1;
-    if (has0 && r0 == k - 1) *mkey = my0;
-    if (has1 && r1 == k - 1) *mkey = my1;
+    if (has0 && r0 == k - 1) {
+        *mkey = my0;
+        if (gbound) atomicMax(gbound, (unsigned)(my0 >> 32));
+    }
+    if (has1 && r1 == k - 1) {
+        *mkey = my1;
+        if (gbound) atomicMax(gbound, (unsigned)(my1 >> 32));
+    }
     if (lane == 0) *cnt = (unsigned)(valid < k ? valid : k);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -222,7 +243,11 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
     u64* my_mkey = mkey_all + lrow;
     unsigned* my_cnt = cnt_all + lrow;
     u64 mkey = sentinel_key(a.min_similarity);  // register copy of the row's threshold key
-    float thr = a.min_similarity;               // its score part
+    float thr = a.min_similarity;               // max(its score part, the row's global bound)
+    float gbf = a.min_similarity;               // last value read from the global bound
+    // padded rows (>= nq) repeat the last real row but without its self exclusion:
+    // they neither read nor publish bounds
+    unsigned* my_gb = (!GRAM && q0 + lrow < a.nq) ? a.bound + q0 + lrow : nullptr;
 
     // ---- staging geometry: thread -> (row r + 32 i, 16-byte chunk c) ----
     const int sc = tid & 7;
@@ -282,6 +307,9 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
             ++nct;
         }
         if (it + 1 < total) load_regs(nct, nkbi);
+        unsigned gb_bits = 0u;
+        if (!GRAM && kb == 0 && my_gb)  // consumed a whole tile later: latency is free
+            gb_bits = __hip_atomic_load(my_gb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -312,6 +340,10 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
                 }
             }
         }
+        if (!GRAM && kb == 0 && my_gb) {
+            gbf = fmaxf(gbf, ordered_to_f32(gb_bits));
+            thr = fmaxf(thr, gbf);
+        }
         if (!GRAM && kb == nkb - 1) {
             // ------------------------- epilogue -------------------------
             const int64_t col0 = (int64_t)ct * BN;
@@ -336,6 +368,12 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
                         if (c == grow) acc[j][r] = -INFINITY;
                     }
             }
+#ifdef TVBF_DIAG_NO_EPILOGUE  // timing-only build: keep the accumulators alive, select nothing
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[j][r]));
+#else
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float m = acc[j][0];
@@ -366,18 +404,20 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
                                 while (full) {
                                     const int l = (int)__builtin_ctzll(full) & 31;
                                     const int row = wave * 32 + l;
+                                    const int64_t qr = q0 + row;
                                     compact_row(buf_all + (size_t)row * a.cap, cnt_all + row, mkey_all + row, a.k,
-                                                a.cap, lane);
+                                                a.cap, lane, qr < a.nq ? a.bound + qr : nullptr);
                                     full &= ~((1ull << l) | (1ull << (l + 32)));
                                 }
                                 mkey = *my_mkey;
-                                thr = ordered_to_f32((uint32_t)(mkey >> 32));
-                                cand = cand && key > mkey;
+                                thr = fmaxf(ordered_to_f32((uint32_t)(mkey >> 32)), gbf);
+                                cand = cand && v >= thr && key > mkey;
                             }
                         }
                     }
                 }
             }
+#endif
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -397,11 +437,16 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
         const int row = wave * 32 + l;
         const int64_t qr = q0 + row;
         if (qr >= a.nq) break;
-        compact_row(buf_all + (size_t)row * a.cap, cnt_all + row, mkey_all + row, a.k, a.cap, lane);
+        compact_row(buf_all + (size_t)row * a.cap, cnt_all + row, mkey_all + row, a.k, a.cap, lane, a.bound + qr);
         const int have = (int)cnt_all[row];
         u64* dst = a.partial + ((int64_t)split * a.nq + qr) * a.k;
         for (int i = lane; i < a.k; i += 64) dst[i] = i < have ? buf_all[(size_t)row * a.cap + i] : empty;
     }
+}
+
+__global__ __launch_bounds__(256) void bound_init_kernel(unsigned* __restrict__ bound, int64_t nq, unsigned v) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nq) bound[i] = v;
 }
 
 // --------------------------------------------------------------------------
@@ -535,7 +580,17 @@ static Plan make_plan(int64_t nq, int64_t n, int k, int cus) {
         }
     }
     p.splits = best;
+    if (const char* e = getenv("TVBF_SPLITS")) {  // tuning aid; any value gives the same result
+        const int v = atoi(e);
+        if (v >= 1 && v <= max_s) p.splits = v;
+    }
     return p;
+}
+
+// workspace = [splits x nq x k keys][nq bound words, padded to 16 bytes]
+static size_t topk_partial_bytes(const Plan& p, int64_t nq, int k) { return (size_t)p.splits * (size_t)nq * (size_t)k * 8; }
+static size_t topk_workspace_need(const Plan& p, int64_t nq, int k) {
+    return topk_partial_bytes(p, nq, k) + ((size_t)nq * 4 + 15) / 16 * 16;
 }
 
 static int fill_blocks(BlockDesc* bd, const int32_t* off, const float* scale, int nb, int64_t d) {
@@ -578,7 +633,7 @@ size_t tvbf_topk_workspace_bytes(int64_t nq, int64_t n, int64_t d, int k) {
     (void)d;
     if (nq < 1 || n < 1 || k < 1 || k > TVBF_MAX_K) return 0;
     const Plan p = make_plan(nq, n, k, device_cus());
-    return (size_t)p.splits * (size_t)nq * (size_t)k * 8;
+    return topk_workspace_need(p, nq, k);
 }
 
 int tvbf_cosine_topk_f32(const float* Zq, int64_t nq, int64_t q_row0, const float* Zall, int64_t n, int64_t d,
@@ -597,7 +652,7 @@ int tvbf_cosine_topk_f32(const float* Zq, int64_t nq, int64_t q_row0, const floa
     if (min_similarity < -FLT_MAX) min_similarity = -FLT_MAX;  // -inf marks masked columns
 
     const Plan p = make_plan(nq, n, k, device_cus());
-    const size_t need = (size_t)p.splits * (size_t)nq * (size_t)k * 8;
+    const size_t need = topk_workspace_need(p, nq, k);
     if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15))
         return fail(TVBF_E_BAD_SHAPE, "workspace must be 16-byte aligned and >= %zu bytes", need);
     const int64_t grid = (int64_t)p.row_blocks * p.splits;
@@ -611,6 +666,9 @@ int tvbf_cosine_topk_f32(const float* Zq, int64_t nq, int64_t q_row0, const floa
     a.zq = Zq;
     a.zall = Zall;
     a.partial = reinterpret_cast<u64*>(workspace);
+    a.bound = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) + topk_partial_bytes(p, nq, k));
+    hipLaunchKernelGGL(bound_init_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       a.bound, nq, f32_to_ordered(min_similarity));
     a.nq = nq;
     a.n = n;
     a.q_row0 = q_row0;
@@ -657,6 +715,7 @@ int tvbf_gram_f32(const float* Zq, int64_t nq, const float* Zall, int64_t n, int
     a.splits = a.col_tiles;  // one tile per workgroup
     a.gram = out;
     a.ldo = ldo;
+    a.bound = nullptr;
     const int64_t grid = (int64_t)a.row_blocks * a.splits;
     if (grid > INT32_MAX) return fail(TVBF_E_BAD_ARG, "too many workgroups");
     hipLaunchKernelGGL(cosine_tile_kernel<true>, dim3((unsigned)grid), dim3(TOPK_THREADS),

@@ -14,7 +14,8 @@ from pathlib import Path
 
 CSRC = Path(__file__).resolve().parent / "csrc"
 INCLUDE = Path(__file__).resolve().parent.parent / "include"
-LIB_PATH = CSRC / "libtvbf.so"
+# TVBF_LIB selects another build of the same ABI (timing-only diagnostic variants under build/)
+LIB_PATH = Path(os.environ["TVBF_LIB"]) if os.environ.get("TVBF_LIB") else CSRC / "libtvbf.so"
 SOURCES = [CSRC / "tvbf_kernels.hip", CSRC / "tvbf_stats.hip"]
 
 # Every symbol include/tvbf.h declares.
