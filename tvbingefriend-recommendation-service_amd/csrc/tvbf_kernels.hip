@@ -187,8 +187,20 @@ __device__ static inline void compact_row(u64* buf, unsigned* cnt, u64* mkey, in
     const u64 my0 = has0 ? buf[lane] : 0ull;
     const u64 my1 = has1 ? buf[lane + 64] : 0ull;
     int r0 = 0, r1 = 0;
+    int i = 0;
 #pragma nounroll
-    for (int i = 0; i < valid; ++i) {
+    for (; i + 8 <= valid; i += 8) {  // eight independent broadcast reads in flight
+        u64 o[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) o[u] = buf[i + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            r0 += o[u] > my0 ? 1 : 0;
+            r1 += o[u] > my1 ? 1 : 0;
+        }
+    }
+#pragma nounroll
+    for (; i < valid; ++i) {
         const u64 o = buf[i];  // same address in every lane: LDS broadcast
         r0 += o > my0 ? 1 : 0;
         r1 += o > my1 ? 1 : 0;
@@ -379,15 +391,27 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
                 float m = acc[j][0];
 #pragma unroll
                 for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[j][r]);
+#ifdef TVBF_DIAG_PRETEST_ONLY  // timing-only build: the rejection test alone
+                asm volatile("" ::"v"(m));
+                if (false) {
+#else
                 if (__any(m >= thr)) {
+#endif
 #pragma unroll
                     for (int r = 0; r < 16; ++r) scratch[r * 64 + lane] = acc[j][r];
-#pragma nounroll
-                    for (int r = 0; r < 16; ++r) {
+                    // which of this lane's 16 scores pass: a bit mask built from registers
+                    unsigned bits = 0u;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) bits |= acc[j][r] >= thr ? (1u << r) : 0u;
+                    // one round per remaining candidate of the busiest lane
+                    while (__any(bits != 0u)) {
+                        const bool has = bits != 0u;
+                        const int r = has ? __builtin_ctz(bits) : 0;
+                        bits &= bits - 1u;
                         const float v = scratch[r * 64 + lane];
                         const int c = (int)col0 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * half;
                         const u64 key = make_key(v, c);
-                        bool cand = v >= thr && key > mkey;
+                        bool cand = has && v >= thr && key > mkey;
                         while (__any(cand)) {
                             if (cand) {
                                 const unsigned pos = atomicAdd(my_cnt, 1u);
