@@ -41,8 +41,8 @@ def test_argument_validation_needs_no_gpu(pkg):
     p = ctypes.c_void_p(16)  # never dereferenced: validation fails first
     rc = lib.tvbf_cosine_topk_f32(p, 4, 0, p, 4, 32, 32, 0, 0.1, 1, p, p, p, p, 1 << 20, None)
     assert rc == -1 and b"k must be" in lib.tvbf_last_error()
-    rc = lib.tvbf_cosine_topk_f32(p, 4, 0, p, 4, 30, 32, 5, 0.1, 1, p, p, p, p, 1 << 20, None)
-    assert rc == -2 and b"multiples of 4" in lib.tvbf_last_error()
+    rc = lib.tvbf_cosine_topk_f32(p, 4, 0, p, 4, 36, 36, 5, 0.1, 1, p, p, p, p, 1 << 20, None)
+    assert rc == -2 and b"multiple of 32" in lib.tvbf_last_error()
     rc = lib.tvbf_cosine_topk_f32(None, 4, 0, p, 4, 32, 32, 5, 0.1, 1, p, p, p, p, 1 << 20, None)
     assert rc == -1
     rc = lib.tvbf_cosine_topk_f32(p, 4, 0, p, 4, 32, 32, 5, float("nan"), 1, p, p, p, p, 1 << 20, None)

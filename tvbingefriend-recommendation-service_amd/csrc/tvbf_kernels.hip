@@ -131,7 +131,11 @@ __global__ __launch_bounds__(256) void normalize_blocks_kernel(const float* __re
 // ds_read_b128 lane group then fall on sixteen different 16-byte bank slots.
 // --------------------------------------------------------------------------
 constexpr int BM = 128;
-constexpr int BN = 128;
+#ifndef TVBF_BN
+#define TVBF_BN 128
+#endif
+constexpr int BN = TVBF_BN;  // column shows per tile
+constexpr int NJ = BN / 32;  // 32x32 MFMA sub-tiles per wave and tile
 constexpr int BK = 32;
 constexpr int LDT = BK + 4;
 constexpr int TOPK_THREADS = 256;
@@ -150,15 +154,13 @@ struct TopkArgs {
     int64_t ldo;
 };
 
-__device__ static inline f32x4 load_chunk(const float* p, bool valid) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+__device__ static inline f32x4 load_chunk(const char* p) {
 #ifdef TVBF_DIAG_NO_LOADS  // timing-only build: no global traffic
     asm volatile("" ::"v"(p));
-    v[0] = valid ? 1.f : 0.f;
+    return f32x4{1.f, 0.f, 0.f, 0.f};
 #else
-    if (valid) v = *reinterpret_cast<const f32x4*>(p);
+    return *reinterpret_cast<const f32x4*>(p);
 #endif
-    return v;
 }
 
 // Per-row candidate buffers.  Every query row owns `cap` = K + slack 64-bit keys
@@ -264,29 +266,35 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
     // ---- staging geometry: thread -> (row r + 32 i, 16-byte chunk c) ----
     const int sc = tid & 7;
     const int sr = tid >> 3;
-    const float* qsrc[4];
+    // Global addresses are a wave-uniform base (tile origin + k offset, in SGPRs) plus a
+    // per-thread 32-bit byte offset that changes only from tile to tile, so a k-block costs
+    // no vector arithmetic for addressing.  Rows past the end are clamped to the last row.
+    unsigned qoff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        int64_t r = q0 + sr + 32 * i;
-        if (r > a.nq - 1) r = a.nq - 1;
-        qsrc[i] = a.zq + r * a.ld + sc * 4;
+        int64_t r = sr + 32 * i;
+        if (q0 + r > a.nq - 1) r = a.nq - 1 - q0;
+        qoff[i] = (unsigned)((r * a.ld + sc * 4) * 4);
     }
+    const char* qbase = reinterpret_cast<const char*>(a.zq + q0 * a.ld);
     float* qdst = tileQ + sr * LDT + sc * 4;
     float* cdst = tileC + sr * LDT + sc * 4;
 
-    const int nkb = (a.d + BK - 1) / BK;
+    const int nkb = a.d / BK;  // the host guarantees d % BK == 0
     const int total = (tile_end - tile_begin) * nkb;
 
-    f32x4 rq[4], rc[4];
+    f32x4 rq[4], rc[NJ];
     auto load_regs = [&](int ct, int kb) {
-        const int kof = kb * BK;
-        const bool valid = (kof + sc * 4) < a.d;
+        const char* qb = qbase + (size_t)kb * (BK * 4);
+        const char* cb = reinterpret_cast<const char*>(a.zall + (int64_t)ct * BN * a.ld) + (size_t)kb * (BK * 4);
+        const int64_t last = a.n - 1 - (int64_t)ct * BN;  // last valid row of this tile
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            rq[i] = load_chunk(qsrc[i] + kof, valid);
-            int64_t r = (int64_t)ct * BN + sr + 32 * i;
-            if (r > a.n - 1) r = a.n - 1;
-            rc[i] = load_chunk(a.zall + r * a.ld + sc * 4 + kof, valid);
+        for (int i = 0; i < 4; ++i) rq[i] = load_chunk(qb + qoff[i]);
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) {
+            int64_t r = sr + 32 * i;
+            if (r > last) r = last;
+            rc[i] = load_chunk(cb + (unsigned)((r * a.ld + sc * 4) * 4));
         }
     };
 
@@ -294,9 +302,9 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
     const float* c_lds = tileC + (lane & 31) * LDT + half * 4;
     float* scratch = tileQ + wave * 32 * LDT;  // this wave's own query rows, free in the epilogue
 
-    f32x16 acc[4];
+    f32x16 acc[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
@@ -304,14 +312,18 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
     if (total > 0) load_regs(ct, kb);
     __syncthreads();  // lists initialised
 
+#ifdef TVBF_DIAG_NO_BARRIER  // timing-only build (results are wrong)
+#define TILE_SYNC() __builtin_amdgcn_wave_barrier()
+#else
+#define TILE_SYNC() __syncthreads()
+#endif
     for (int it = 0; it < total; ++it) {
-        __syncthreads();  // everyone is done with the previous LDS tile (and epilogue scratch)
+        TILE_SYNC();  // everyone is done with the previous LDS tile (and epilogue scratch)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x4*>(qdst + 32 * i * LDT) = rq[i];
-            *reinterpret_cast<f32x4*>(cdst + 32 * i * LDT) = rc[i];
-        }
-        __syncthreads();
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(qdst + 32 * i * LDT) = rq[i];
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) *reinterpret_cast<f32x4*>(cdst + 32 * i * LDT) = rc[i];
+        TILE_SYNC();
         // prefetch the next k-block into registers while the MFMAs run
         int nct = ct, nkbi = kb + 1;
         if (nkbi == nkb) {
@@ -323,26 +335,49 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
         if (!GRAM && kb == 0 && my_gb)  // consumed a whole tile later: latency is free
             gb_bits = __hip_atomic_load(my_gb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
+        // Fragment reads run one 8-deep step ahead of the MFMAs that consume them, so the
+        // matrix pipe does not drain while LDS data is in flight.
+#ifdef TVBF_DIAG_NO_LDSREAD  // timing-only build: operands never leave registers
+#define FRAG_LOAD(p) f32x4{(float)tid, 1.f, 2.f, (float)it}
+#else
+#define FRAG_LOAD(p) (*reinterpret_cast<const f32x4*>(p))
+#endif
+        f32x4 qf = FRAG_LOAD(q_lds);
+        f32x4 cf[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) cf[j] = FRAG_LOAD(c_lds + j * 32 * LDT);
+        __builtin_amdgcn_sched_group_barrier(0x100, NJ + 1, 0);  // the reads of step 0
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const f32x4 qf = *reinterpret_cast<const f32x4*>(q_lds + t * 8);
-            f32x4 cf[4];
+            f32x4 qn = qf;
+            f32x4 cn[NJ];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                cf[j] = *reinterpret_cast<const f32x4*>(c_lds + j * 32 * LDT + t * 8);
+            for (int j = 0; j < NJ; ++j) cn[j] = cf[j];
+            if (t < 3) {
+                qn = FRAG_LOAD(q_lds + (t + 1) * 8);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    cn[j] = FRAG_LOAD(c_lds + j * 32 * LDT + (t + 1) * 8);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NJ; ++j)
                     acc[j] = GRAM ? __builtin_amdgcn_mfma_f32_32x32x2f32(qf[i], cf[j][i], acc[j], 0, 0, 0)
                                   : __builtin_amdgcn_mfma_f32_32x32x2f32(cf[j][i], qf[i], acc[j], 0, 0, 0);
+            // pin the order: reads of step t+1 first, then the 4*NJ MFMAs of step t
+            if (t < 3) __builtin_amdgcn_sched_group_barrier(0x100, NJ + 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NJ, 0);
+            qf = qn;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) cf[j] = cn[j];
         }
 
         if (GRAM && kb == nkb - 1) {
             // lane = column (lane & 31) of sub-tile j, registers = query rows of this wave
             const int64_t col0 = (int64_t)ct * BN;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const int64_t c = col0 + 32 * j + (lane & 31);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -363,7 +398,7 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
             // columns past n (last tile only)
             if (col0 + BN > a.n) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int64_t c = col0 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -373,7 +408,7 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
             // the show itself (by index, whatever its score)
             if (a.exclude_self && col0 < a.q_row0 + q0 + BM && col0 + BN > a.q_row0 + q0) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int64_t c = col0 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -382,12 +417,12 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
             }
 #ifdef TVBF_DIAG_NO_EPILOGUE  // timing-only build: keep the accumulators alive, select nothing
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[j][r]));
 #else
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 float m = acc[j][0];
 #pragma unroll
                 for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[j][r]);
@@ -443,7 +478,7 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
             }
 #endif
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
         }
@@ -568,13 +603,19 @@ static int device_cus() {
 // several accepted candidates.  K <= 30 keeps two workgroups per CU (<= 80 KB
 // each); K <= 52 uses 64 entries (one key per lane in a compaction).
 static int topk_cap(int k) {
+#if TVBF_BN == 256
+    if (k <= 20) return k + 4;  // experiment: keeps two workgroups per CU
+#endif
     if (k <= 30) return k + 12;
     if (k <= 52) return 64;
     return k + 12;
 }
 
 static size_t topk_lds_bytes(int k) {
-    return (size_t)(BM + BN) * LDT * sizeof(float) + (size_t)BM * topk_cap(k) * 8 + (size_t)BM * 8 + (size_t)BM * 4;
+    size_t pad = 0;
+    if (const char* e = getenv("TVBF_LDS_PAD")) pad = (size_t)atoi(e);  // tuning aid: forces one workgroup per CU
+    return pad + (size_t)(BM + BN) * LDT * sizeof(float) + (size_t)BM * topk_cap(k) * 8 + (size_t)BM * 8 +
+           (size_t)BM * 4;
 }
 
 // Column splits trade tail balance (more, shorter workgroups) against repeated
@@ -669,8 +710,10 @@ int tvbf_cosine_topk_f32(const float* Zq, int64_t nq, int64_t q_row0, const floa
     if (nq < 0 || n < 1 || d < 1 || q_row0 < 0) return fail(TVBF_E_BAD_ARG, "bad nq, n, d or q_row0");
     if (k < 1 || k > TVBF_MAX_K) return fail(TVBF_E_BAD_ARG, "k must be 1..%d", TVBF_MAX_K);
     if (n > INT32_MAX - BN || d > INT32_MAX - BK) return fail(TVBF_E_BAD_ARG, "n or d too large");
-    if ((d & 3) || (ld & 3) || ld < d) return fail(TVBF_E_BAD_SHAPE, "d and ld must be multiples of 4, ld >= d");
+    if ((d % BK) || (ld & 3) || ld < d)
+        return fail(TVBF_E_BAD_SHAPE, "d must be a multiple of 32 and ld a multiple of 4, ld >= d");
     if (((uintptr_t)Zq & 15) || ((uintptr_t)Zall & 15)) return fail(TVBF_E_BAD_SHAPE, "Z must be 16-byte aligned");
+    if (ld > (INT32_MAX / 4) / (BM + BN)) return fail(TVBF_E_BAD_SHAPE, "ld too large");
     if (min_similarity != min_similarity) return fail(TVBF_E_BAD_ARG, "min_similarity is NaN");
     if (nq == 0) return TVBF_OK;
     if (min_similarity < -FLT_MAX) min_similarity = -FLT_MAX;  // -inf marks masked columns
@@ -721,8 +764,10 @@ int tvbf_gram_f32(const float* Zq, int64_t nq, const float* Zall, int64_t n, int
     if (!Zq || !Zall || !out) return fail(TVBF_E_BAD_ARG, "null pointer argument");
     if (nq < 0 || n < 1 || d < 1) return fail(TVBF_E_BAD_ARG, "bad nq, n or d");
     if (n > INT32_MAX - BN || d > INT32_MAX - BK) return fail(TVBF_E_BAD_ARG, "n or d too large");
-    if ((d & 3) || (ld & 3) || ld < d) return fail(TVBF_E_BAD_SHAPE, "d and ld must be multiples of 4, ld >= d");
+    if ((d % BK) || (ld & 3) || ld < d)
+        return fail(TVBF_E_BAD_SHAPE, "d must be a multiple of 32 and ld a multiple of 4, ld >= d");
     if (((uintptr_t)Zq & 15) || ((uintptr_t)Zall & 15)) return fail(TVBF_E_BAD_SHAPE, "Z must be 16-byte aligned");
+    if (ld > (INT32_MAX / 4) / (BM + BN)) return fail(TVBF_E_BAD_SHAPE, "ld too large");
     if (ldo < n) return fail(TVBF_E_BAD_SHAPE, "ldo must be >= n");
     if (nq == 0) return TVBF_OK;
     TopkArgs a;
