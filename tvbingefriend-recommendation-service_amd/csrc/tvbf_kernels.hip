@@ -604,7 +604,7 @@ static int device_cus() {
 // each); K <= 52 uses 64 entries (one key per lane in a compaction).
 static int topk_cap(int k) {
 #if TVBF_BN == 256
-    if (k <= 20) return k + 4;  // experiment: keeps two workgroups per CU
+    if (k <= 20) return 24;  // keeps two workgroups per CU with the wider column tile
 #endif
     if (k <= 30) return k + 12;
     if (k <= 52) return 64;
