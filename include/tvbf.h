@@ -102,6 +102,36 @@ int tvbf_cosine_topk_f32(const float* Zq, int64_t nq, int64_t q_row0, const floa
                          size_t workspace_bytes, void* stream);
 
 /*
+ * Incremental form of tvbf_cosine_topk_f32 for callers that receive the columns
+ * in pieces -- a row shard of a multi-GPU job scores its own rows against its
+ * own shard while the all-gather of the other shards is still in flight, then
+ * against the rest.  No counterpart in the reference (it is single-process).
+ *
+ *   tvbf_topk_begin        resets the per-row bounds held at the start of the workspace
+ *   tvbf_topk_accumulate   one fused launch over up to two column ranges
+ *                          (ZcA: nA rows that are global columns colA..colA+nA-1; ZcB likewise,
+ *                          nB may be 0); writes *slots_used partial lists per row into workspace
+ *                          slots slot0, slot0+1, ... (at most max_slots of them)
+ *   tvbf_topk_finish       merges slots 0..slots-1 into out_idx / out_score / out_count
+ *
+ * All calls of one sequence use the same nq, k, min_similarity, workspace and stream.  The total
+ * number of slots may not exceed tvbf_topk_max_slots(k); a workspace of
+ * tvbf_topk_workspace_bytes_for_slots(nq, k, slots) bytes holds `slots` of them.
+ * tvbf_cosine_topk_f32 is begin + one accumulate over all n columns + finish.
+ */
+int tvbf_topk_max_slots(int k);
+size_t tvbf_topk_workspace_bytes_for_slots(int64_t nq, int k, int slots);
+int tvbf_topk_begin(int64_t nq, int k, float min_similarity, void* workspace, size_t workspace_bytes,
+                    void* stream);
+int tvbf_topk_accumulate_f32(const float* Zq, int64_t nq, int64_t q_row0, int64_t d, int64_t ld,
+                             const float* ZcA, int64_t nA, int64_t colA, const float* ZcB, int64_t nB,
+                             int64_t colB, int k, float min_similarity, int exclude_self, void* workspace,
+                             size_t workspace_bytes, int slot0, int max_slots, int* slots_used,
+                             void* stream);
+int tvbf_topk_finish(int64_t nq, int k, int slots, int32_t* out_idx, float* out_score,
+                     int32_t* out_count, const void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * K2 alone -- the dense score matrix, for callers that want it whole (small n):
  * out[i, j] = sum_c Zq[i, c] * Zall[j, c].  With Z one normalised feature block
  * this is sklearn's cosine_similarity(X) of ml/similarity_computer.py:41,58,86;

@@ -22,8 +22,10 @@ SCORE_TOL = 1e-5
 
 
 def check_topk_against_scores(h_rows, row0, k, min_similarity, got_idx, got_score, got_count,
-                              exclude_self=True, tol=SCORE_TOL, what=""):
-    """``h_rows`` holds the oracle's full float64 score rows for the query rows."""
+                              exclude_self=True, tol=SCORE_TOL, what="", check_tie_order=True):
+    """``h_rows`` holds the oracle's full float64 score rows for the query rows.
+    ``check_tie_order`` also demands index order among scores that are equal in fp32
+    (the kernels' rule; a float64 stand-in cannot be held to it)."""
     h_rows = np.asarray(h_rows, dtype=np.float64)
     nq, n = h_rows.shape
     got_idx = np.asarray(got_idx)
@@ -59,7 +61,8 @@ def check_topk_against_scores(h_rows, row0, k, min_similarity, got_idx, got_scor
         d = np.diff(gs.astype(np.float32))
         assert np.all(d <= 0), f"{what} row {r}: scores not descending"
         same = d == 0
-        assert np.all(np.diff(gi)[same] > 0), f"{what} row {r}: equal scores not in index order"
+        if check_tie_order:
+            assert np.all(np.diff(gi)[same] > 0), f"{what} row {r}: equal scores not in index order"
         # exact index parity away from (near-)ties
         ext = np.full(c + 2, -np.inf)
         ext[0] = np.inf

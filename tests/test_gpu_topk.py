@@ -167,3 +167,74 @@ def test_golden_hybrid(pkg, device):
     check_topk_against_golden(g["idx"], g["sorted_scores"], k, _to_np(top.idx), _to_np(top.score),
                               _to_np(top.count), pair_score=lambda r, cols: zo[r] @ zo[cols].T,
                               min_similarity=float(g["min_similarity"]), what="hybrid_2048")
+
+
+@pytest.mark.parametrize("n,world", [(700, 2), (1000, 8), (333, 3)])
+def test_column_pieces_equal_single_sweep(pkg, device, n, world):
+    """A row shard that scores its own columns first and the rest later (two launches, the second
+    over two ranges) gets, bit for bit, the lists of one sweep over all columns."""
+    import torch
+
+    from tvbingefriend_recommendation_service_amd import engine, sharding
+
+    g, t, p, ty, la = hybrid_like_blocks(n, seed=31, d_genre=16, d_text=90)
+    x = np.ascontiguousarray(np.hstack([g, t, p, ty, la]), dtype=np.float32)
+    offsets, scales = [0, 16, 106, 138], [float(np.sqrt(w)) for w in (0.4, 0.5, 0.1)]
+    z = engine.normalize_blocks(torch.from_numpy(x).to(device), offsets, scales)
+    k, ms = 20, 0.1
+    full = engine.cosine_topk(z, k, ms)
+    for rank in range(world):
+        sh = sharding.shard_bounds(n, world, rank)
+        if sh.rows == 0:
+            continue
+        own, after, before = sharding.column_pieces(sh)
+        zq = z[sh.row0 : sh.row0 + sh.rows].contiguous()  # the rank's own shard, as after normalisation
+        ses = engine.TopkSession(zq, sh.rows, sh.row0, k, ms)
+        assert ses.accumulate((zq, own[1], own[0])) >= 1
+        ses.accumulate((z[after[0]:], after[1], after[0]), (z, before[1], before[0]))
+        top = ses.finish()
+        torch.cuda.synchronize()
+        sl = slice(sh.row0, sh.row0 + sh.rows)
+        assert np.array_equal(_to_np(top.idx), _to_np(full.idx)[sl]), rank
+        assert np.array_equal(_to_np(top.score), _to_np(full.score)[sl]), rank
+        assert np.array_equal(_to_np(top.count), _to_np(full.count)[sl]), rank
+
+
+def test_large_shape_properties(pkg, device):
+    """N = 100k x D = 1024 (the benchmark shape): properties that need no N x N oracle --
+    sampled rows against the float64 oracle, order, self exclusion, shard/full equality."""
+    import torch
+
+    from tvbingefriend_recommendation_service_amd import engine
+
+    n, d, k, ms = 100_000, 1024, 20, 0.1
+    gen = torch.Generator(device=device)
+    gen.manual_seed(5)
+    x = torch.zeros((n, d), device=device)
+    x[:, :32] = (torch.rand((n, 32), generator=gen, device=device) < 0.08).float()
+    text = torch.randn((n, d - 64), generator=gen, device=device).abs_()
+    text *= torch.rand((n, d - 64), generator=gen, device=device) < 0.03
+    x[:, 32 : d - 32] = text
+    del text
+    x[torch.arange(n, device=device), d - 32 + torch.randint(0, 32, (n,), generator=gen, device=device)] = 1.0
+    offsets, weights = [0, 32, d - 32, d], [0.4, 0.5, 0.1]
+    scales = [float(np.sqrt(w)) for w in weights]
+    z = engine.normalize_blocks(x, offsets, scales)
+    top = engine.cosine_topk(z, k, ms)
+    part = engine.cosine_topk(z, k, ms, q_row0=37_500, nq=12_500)
+    torch.cuda.synchronize()
+    idx, score, count = _to_np(top.idx), _to_np(top.score), _to_np(top.count)
+    assert np.array_equal(_to_np(part.idx), idx[37_500:50_000]) and np.array_equal(_to_np(part.score), score[37_500:50_000])
+    valid = idx >= 0
+    assert np.array_equal(valid.sum(axis=1), count) and np.all(valid[:, :-1] >= valid[:, 1:])
+    assert not np.any(idx == np.arange(n)[:, None])
+    assert np.all(np.diff(score, axis=1)[valid[:, 1:]] <= 0) and np.all(score[valid] >= ms)
+    # sampled rows against the oracle (float64 on the host)
+    rows = np.random.default_rng(0).choice(n, size=48, replace=False)
+    xh = x.cpu().numpy().astype(np.float64)
+    zo = so.build_z([xh[:, offsets[b] : offsets[b + 1]] for b in range(3)], weights)
+    del xh
+    h = zo[rows] @ zo.T
+    for o, r in enumerate(rows):
+        check_topk_against_scores(h[o : o + 1], int(r), k, ms, idx[r : r + 1], score[r : r + 1], count[r : r + 1],
+                                  what=f"N=100k row {r}")

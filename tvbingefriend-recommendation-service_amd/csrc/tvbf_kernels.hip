@@ -140,12 +140,22 @@ constexpr int BK = 32;
 constexpr int LDT = BK + 4;
 constexpr int TOPK_THREADS = 256;
 
+// One launch sweeps the concatenation of up to two column ranges (a row shard sees the
+// columns before and after its own rows as two pieces of the gathered matrix); tiles never
+// straddle a range.
+struct ColRange {
+    const float* z;    // first row of the range
+    int64_t n;         // rows (= columns of the score matrix) in the range
+    int64_t col_base;  // global column index of z[0]
+    int tiles;         // ceil(n / BN)
+};
+
 struct TopkArgs {
     const float* zq;
-    const float* zall;
-    u64* partial;  // [splits][nq][k]
+    ColRange rng[2];
+    u64* partial;  // [splits][nq][k], first partial slot of this launch
     unsigned* bound;  // [nq] best known lower bound of every row's K-th score (ordered bits)
-    int64_t nq, n, q_row0, ld;
+    int64_t nq, q_row0, ld;
     int d, k, cap;
     int row_blocks, splits, col_tiles;
     float min_similarity;
@@ -286,8 +296,10 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
     f32x4 rq[4], rc[NJ];
     auto load_regs = [&](int ct, int kb) {
         const char* qb = qbase + (size_t)kb * (BK * 4);
-        const char* cb = reinterpret_cast<const char*>(a.zall + (int64_t)ct * BN * a.ld) + (size_t)kb * (BK * 4);
-        const int64_t last = a.n - 1 - (int64_t)ct * BN;  // last valid row of this tile
+        const ColRange& cr = a.rng[ct >= a.rng[0].tiles ? 1 : 0];
+        const int64_t trow = (int64_t)(ct >= a.rng[0].tiles ? ct - a.rng[0].tiles : ct) * BN;  // tile's first row
+        const char* cb = reinterpret_cast<const char*>(cr.z + trow * a.ld) + (size_t)kb * (BK * 4);
+        const int64_t last = cr.n - 1 - trow;  // last valid row of this tile
 #pragma unroll
         for (int i = 0; i < 4; ++i) rq[i] = load_chunk(qb + qoff[i]);
 #pragma unroll
@@ -375,14 +387,15 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
 
         if (GRAM && kb == nkb - 1) {
             // lane = column (lane & 31) of sub-tile j, registers = query rows of this wave
-            const int64_t col0 = (int64_t)ct * BN;
+            const int64_t col0 = (int64_t)ct * BN;  // dense-matrix mode uses one range only
+            const int64_t n_cols = a.rng[0].n;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int64_t c = col0 + 32 * j + (lane & 31);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int64_t qr = q0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (qr < a.nq && c < a.n) a.gram[qr * a.ldo + c] = acc[j][r];
+                    if (qr < a.nq && c < n_cols) a.gram[qr * a.ldo + c] = acc[j][r];
                     acc[j][r] = 0.f;
                 }
             }
@@ -393,16 +406,19 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
         }
         if (!GRAM && kb == nkb - 1) {
             // ------------------------- epilogue -------------------------
-            const int64_t col0 = (int64_t)ct * BN;
-            const int64_t grow = a.q_row0 + q0 + lrow;  // global index of this lane's query row
-            // columns past n (last tile only)
-            if (col0 + BN > a.n) {
+            const ColRange& cr = a.rng[ct >= a.rng[0].tiles ? 1 : 0];
+            const int64_t trow = (int64_t)(ct >= a.rng[0].tiles ? ct - a.rng[0].tiles : ct) * BN;
+            const int64_t col0 = cr.col_base + trow;    // global column of the tile's first column
+            const int64_t col_end = cr.col_base + cr.n;  // one past the range's last column
+            const int64_t grow = a.q_row0 + q0 + lrow;   // global index of this lane's query row
+            // columns past the end of the range (its last tile only)
+            if (col0 + BN > col_end) {
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int64_t c = col0 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        if (c >= a.n) acc[j][r] = -INFINITY;
+                        if (c >= col_end) acc[j][r] = -INFINITY;
                     }
             }
             // the show itself (by index, whatever its score)
@@ -511,16 +527,18 @@ __global__ __launch_bounds__(256) void bound_init_kernel(unsigned* __restrict__ 
 // --------------------------------------------------------------------------
 // merge of the per-split lists: one wavefront per query row, rank by counting.
 // --------------------------------------------------------------------------
-constexpr int FIN_MAX_KEYS = 1024;  // splits * k
+constexpr int FIN_MAX_KEYS = 2048;  // partial lists per row * k
 
-__global__ __launch_bounds__(256) void topk_finalize_kernel(const u64* __restrict__ partial, int64_t nq,
+constexpr int FIN_ROWS = 2;  // rows (wavefronts) per workgroup
+
+__global__ __launch_bounds__(64 * FIN_ROWS) void topk_finalize_kernel(const u64* __restrict__ partial, int64_t nq,
                                                             int k, int splits, int32_t* __restrict__ out_idx,
                                                             float* __restrict__ out_score,
                                                             int32_t* __restrict__ out_count) {
-    __shared__ u64 buf[4][FIN_MAX_KEYS];
+    __shared__ u64 buf[FIN_ROWS][FIN_MAX_KEYS];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t row = (int64_t)blockIdx.x * FIN_ROWS + wave;
     if (row >= nq) return;
     u64* b = buf[wave];
     const int m = splits * k;
@@ -621,14 +639,14 @@ static size_t topk_lds_bytes(int k) {
 // Column splits trade tail balance (more, shorter workgroups) against repeated
 // list warm-up; every choice gives the same result because the merge applies
 // one total order.
-static Plan make_plan(int64_t nq, int64_t n, int k, int cus) {
+static Plan make_plan(int64_t nq, int col_tiles, int64_t d, int k, int cus, int max_slots) {
     Plan p;
     p.row_blocks = (int)((nq + BM - 1) / BM);
-    p.col_tiles = (int)((n + BN - 1) / BN);
+    p.col_tiles = col_tiles;
     p.lds_bytes = topk_lds_bytes(k);
     p.wg_per_cu = p.lds_bytes * 2 <= 160 * 1024 ? 2 : 1;
     const int64_t slots = (int64_t)cus * p.wg_per_cu;
-    int max_s = FIN_MAX_KEYS / k;
+    int max_s = max_slots;
     if (max_s > 16) max_s = 16;
     if (max_s > p.col_tiles) max_s = p.col_tiles;
     if (max_s < 1) max_s = 1;
@@ -638,7 +656,13 @@ static Plan make_plan(int64_t nq, int64_t n, int k, int cus) {
         const int64_t wgs = (int64_t)p.row_blocks * s;
         const int64_t rounds = (wgs + slots - 1) / slots;
         const int64_t tiles = (p.col_tiles + s - 1) / s;
-        const double cost = (double)rounds * ((double)tiles + 0.5);  // 0.5 tile ~ warm-up + merge
+        // per workgroup: its tiles plus the list warm-up and final merge (about 400 fp32
+        // columns' worth of MFMA time, measured); a workgroup alone on its CU runs ~0.6x as long
+        double warm = 400.0 / (double)(d > 0 ? d : 1);
+        if (warm < 0.2) warm = 0.2;
+        if (warm > 4.0) warm = 4.0;
+        const double pace = wgs <= cus ? 0.6 : 1.0;
+        const double cost = (double)rounds * ((double)tiles + warm) * pace;
         if (cost < best_cost * 0.999) {
             best_cost = cost;
             best = s;
@@ -652,11 +676,14 @@ static Plan make_plan(int64_t nq, int64_t n, int k, int cus) {
     return p;
 }
 
-// workspace = [splits x nq x k keys][nq bound words, padded to 16 bytes]
-static size_t topk_partial_bytes(const Plan& p, int64_t nq, int k) { return (size_t)p.splits * (size_t)nq * (size_t)k * 8; }
-static size_t topk_workspace_need(const Plan& p, int64_t nq, int k) {
-    return topk_partial_bytes(p, nq, k) + ((size_t)nq * 4 + 15) / 16 * 16;
-}
+// Partial lists the merge kernel can take per row.
+static int max_merge_slots(int k) { return k < 1 ? 0 : FIN_MAX_KEYS / k; }
+
+static int tiles_of(int64_t n) { return (int)((n + BN - 1) / BN); }
+
+// workspace = [nq bound words, padded to 16 bytes][slot 0: nq x k keys][slot 1] ...
+static size_t ws_bound_bytes(int64_t nq) { return ((size_t)nq * 4 + 15) / 16 * 16; }
+static size_t ws_slot_bytes(int64_t nq, int k) { return (size_t)nq * (size_t)k * 8; }
 
 static int fill_blocks(BlockDesc* bd, const int32_t* off, const float* scale, int nb, int64_t d) {
     if (nb < 1 || nb > TVBF_MAX_BLOCKS || !off || !scale)
@@ -695,10 +722,127 @@ int tvbf_normalize_blocks_f32(const float* X, int64_t n, int64_t d, int64_t ldx,
 }
 
 size_t tvbf_topk_workspace_bytes(int64_t nq, int64_t n, int64_t d, int k) {
-    (void)d;
     if (nq < 1 || n < 1 || k < 1 || k > TVBF_MAX_K) return 0;
-    const Plan p = make_plan(nq, n, k, device_cus());
-    return topk_workspace_need(p, nq, k);
+    const Plan p = make_plan(nq, tiles_of(n), d, k, device_cus(), max_merge_slots(k));
+    return ws_bound_bytes(nq) + (size_t)p.splits * ws_slot_bytes(nq, k);
+}
+
+size_t tvbf_topk_workspace_bytes_for_slots(int64_t nq, int k, int slots) {
+    if (nq < 1 || k < 1 || k > TVBF_MAX_K || slots < 1) return 0;
+    return ws_bound_bytes(nq) + (size_t)slots * ws_slot_bytes(nq, k);
+}
+
+int tvbf_topk_max_slots(int k) { return (k < 1 || k > TVBF_MAX_K) ? 0 : max_merge_slots(k); }
+
+static int check_topk_common(int64_t nq, int k, const void* workspace) {
+    if (nq < 0) return fail(TVBF_E_BAD_ARG, "bad nq");
+    if (k < 1 || k > TVBF_MAX_K) return fail(TVBF_E_BAD_ARG, "k must be 1..%d", TVBF_MAX_K);
+    if (!workspace || ((uintptr_t)workspace & 15)) return fail(TVBF_E_BAD_SHAPE, "workspace must be non-null and 16-byte aligned");
+    return TVBF_OK;
+}
+
+int tvbf_topk_begin(int64_t nq, int k, float min_similarity, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_topk_common(nq, k, workspace);
+    if (rc) return rc;
+    if (min_similarity != min_similarity) return fail(TVBF_E_BAD_ARG, "min_similarity is NaN");
+    if (workspace_bytes < ws_bound_bytes(nq)) return fail(TVBF_E_BAD_SHAPE, "workspace too small");
+    if (nq == 0) return TVBF_OK;
+    if (min_similarity < -FLT_MAX) min_similarity = -FLT_MAX;  // -inf marks masked columns
+    hipLaunchKernelGGL(bound_init_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<unsigned*>(workspace), nq, f32_to_ordered(min_similarity));
+    HIP_TRY(hipGetLastError());
+    return TVBF_OK;
+}
+
+// every argument check of an accumulate call; runs before any device work
+static int validate_accumulate(const float* Zq, int64_t nq, int64_t q_row0, int64_t d, int64_t ld, const float* ZcA,
+                               int64_t nA, int64_t colA, const float* ZcB, int64_t nB, int64_t colB, int k,
+                               float min_similarity, const void* workspace, int slot0, int max_slots) {
+    int rc = check_topk_common(nq, k, workspace);
+    if (rc) return rc;
+    if (!Zq) return fail(TVBF_E_BAD_ARG, "null pointer argument");
+    if (nA < 0 || nB < 0 || colA < 0 || colB < 0 || q_row0 < 0 || d < 1) return fail(TVBF_E_BAD_ARG, "bad sizes");
+    if ((nA > 0 && !ZcA) || (nB > 0 && !ZcB)) return fail(TVBF_E_BAD_ARG, "null column range");
+    if (colA + nA > INT32_MAX - BN || colB + nB > INT32_MAX - BN || d > INT32_MAX - BK)
+        return fail(TVBF_E_BAD_ARG, "column index or d too large");
+    if ((d % BK) || (ld & 3) || ld < d)
+        return fail(TVBF_E_BAD_SHAPE, "d must be a multiple of 32 and ld a multiple of 4, ld >= d");
+    if (((uintptr_t)Zq & 15) || ((uintptr_t)ZcA & 15) || ((uintptr_t)ZcB & 15))
+        return fail(TVBF_E_BAD_SHAPE, "Z must be 16-byte aligned");
+    if (ld > (INT32_MAX / 4) / (BM + BN)) return fail(TVBF_E_BAD_SHAPE, "ld too large");
+    if (min_similarity != min_similarity) return fail(TVBF_E_BAD_ARG, "min_similarity is NaN");
+    if (slot0 < 0 || max_slots < 1 || slot0 + max_slots > max_merge_slots(k))
+        return fail(TVBF_E_BAD_ARG, "slot range must lie in [0, %d)", max_merge_slots(k));
+    return TVBF_OK;
+}
+
+int tvbf_topk_accumulate_f32(const float* Zq, int64_t nq, int64_t q_row0, int64_t d, int64_t ld, const float* ZcA,
+                             int64_t nA, int64_t colA, const float* ZcB, int64_t nB, int64_t colB, int k,
+                             float min_similarity, int exclude_self, void* workspace, size_t workspace_bytes,
+                             int slot0, int max_slots, int* slots_used, void* stream) {
+    if (!slots_used) return fail(TVBF_E_BAD_ARG, "slots_used must be non-null");
+    *slots_used = 0;
+    int rc = validate_accumulate(Zq, nq, q_row0, d, ld, ZcA, nA, colA, ZcB, nB, colB, k, min_similarity, workspace,
+                                 slot0, max_slots);
+    if (rc) return rc;
+    if (nq == 0 || nA + nB == 0) return TVBF_OK;
+    if (min_similarity < -FLT_MAX) min_similarity = -FLT_MAX;
+    if (nA == 0) {  // keep the first range non-empty
+        ZcA = ZcB, nA = nB, colA = colB;
+        nB = 0;
+    }
+
+    const int tiles = tiles_of(nA) + (nB ? tiles_of(nB) : 0);
+    const Plan p = make_plan(nq, tiles, d, k, device_cus(), max_slots);
+    const size_t need = ws_bound_bytes(nq) + (size_t)(slot0 + p.splits) * ws_slot_bytes(nq, k);
+    if (workspace_bytes < need) return fail(TVBF_E_BAD_SHAPE, "workspace must be >= %zu bytes", need);
+    const int64_t grid = (int64_t)p.row_blocks * p.splits;
+    if (grid > INT32_MAX) return fail(TVBF_E_BAD_ARG, "too many workgroups");
+    if (p.lds_bytes > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(cosine_tile_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
+    TopkArgs a;
+    memset(&a, 0, sizeof(a));
+    a.zq = Zq;
+    a.rng[0] = ColRange{ZcA, nA, colA, tiles_of(nA)};
+    a.rng[1] = ColRange{nB ? ZcB : ZcA, nB, colB, nB ? tiles_of(nB) : 0};
+    char* ws = reinterpret_cast<char*>(workspace);
+    a.bound = reinterpret_cast<unsigned*>(ws);
+    a.partial = reinterpret_cast<u64*>(ws + ws_bound_bytes(nq) + (size_t)slot0 * ws_slot_bytes(nq, k));
+    a.nq = nq;
+    a.q_row0 = q_row0;
+    a.ld = ld;
+    a.d = (int)d;
+    a.k = k;
+    a.cap = topk_cap(k);
+    a.row_blocks = p.row_blocks;
+    a.splits = p.splits;
+    a.col_tiles = tiles;
+    a.min_similarity = min_similarity;
+    a.exclude_self = exclude_self;
+    hipLaunchKernelGGL(cosine_tile_kernel<false>, dim3((unsigned)grid), dim3(TOPK_THREADS), p.lds_bytes,
+                       (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    *slots_used = p.splits;
+    return TVBF_OK;
+}
+
+int tvbf_topk_finish(int64_t nq, int k, int slots, int32_t* out_idx, float* out_score, int32_t* out_count,
+                     const void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_topk_common(nq, k, workspace);
+    if (rc) return rc;
+    if (!out_idx || !out_score || !out_count) return fail(TVBF_E_BAD_ARG, "null pointer argument");
+    if (slots < 0 || slots > max_merge_slots(k)) return fail(TVBF_E_BAD_ARG, "slots must be 0..%d", max_merge_slots(k));
+    if (workspace_bytes < ws_bound_bytes(nq) + (size_t)slots * ws_slot_bytes(nq, k))
+        return fail(TVBF_E_BAD_SHAPE, "workspace smaller than the slots it is said to hold");
+    if (nq == 0) return TVBF_OK;
+    const char* ws = reinterpret_cast<const char*>(workspace);
+    hipLaunchKernelGGL(topk_finalize_kernel, dim3((unsigned)((nq + FIN_ROWS - 1) / FIN_ROWS)), dim3(64 * FIN_ROWS), 0,
+                       (hipStream_t)stream,
+                       reinterpret_cast<const u64*>(ws + ws_bound_bytes(nq)), nq, k, slots, out_idx, out_score,
+                       out_count);
+    HIP_TRY(hipGetLastError());
+    return TVBF_OK;
 }
 
 int tvbf_cosine_topk_f32(const float* Zq, int64_t nq, int64_t q_row0, const float* Zall, int64_t n, int64_t d,
@@ -707,56 +851,19 @@ int tvbf_cosine_topk_f32(const float* Zq, int64_t nq, int64_t q_row0, const floa
                          void* stream) {
     if (!Zq || !Zall || !out_idx || !out_score || !out_count)
         return fail(TVBF_E_BAD_ARG, "null pointer argument");
-    if (nq < 0 || n < 1 || d < 1 || q_row0 < 0) return fail(TVBF_E_BAD_ARG, "bad nq, n, d or q_row0");
-    if (k < 1 || k > TVBF_MAX_K) return fail(TVBF_E_BAD_ARG, "k must be 1..%d", TVBF_MAX_K);
-    if (n > INT32_MAX - BN || d > INT32_MAX - BK) return fail(TVBF_E_BAD_ARG, "n or d too large");
-    if ((d % BK) || (ld & 3) || ld < d)
-        return fail(TVBF_E_BAD_SHAPE, "d must be a multiple of 32 and ld a multiple of 4, ld >= d");
-    if (((uintptr_t)Zq & 15) || ((uintptr_t)Zall & 15)) return fail(TVBF_E_BAD_SHAPE, "Z must be 16-byte aligned");
-    if (ld > (INT32_MAX / 4) / (BM + BN)) return fail(TVBF_E_BAD_SHAPE, "ld too large");
-    if (min_similarity != min_similarity) return fail(TVBF_E_BAD_ARG, "min_similarity is NaN");
-    if (nq == 0) return TVBF_OK;
-    if (min_similarity < -FLT_MAX) min_similarity = -FLT_MAX;  // -inf marks masked columns
-
-    const Plan p = make_plan(nq, n, k, device_cus());
-    const size_t need = topk_workspace_need(p, nq, k);
-    if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15))
-        return fail(TVBF_E_BAD_SHAPE, "workspace must be 16-byte aligned and >= %zu bytes", need);
-    const int64_t grid = (int64_t)p.row_blocks * p.splits;
-    if (grid > INT32_MAX) return fail(TVBF_E_BAD_ARG, "too many workgroups");
-
-    if (p.lds_bytes > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(cosine_tile_kernel<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
-
-    TopkArgs a;
-    a.zq = Zq;
-    a.zall = Zall;
-    a.partial = reinterpret_cast<u64*>(workspace);
-    a.bound = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) + topk_partial_bytes(p, nq, k));
-    hipLaunchKernelGGL(bound_init_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       a.bound, nq, f32_to_ordered(min_similarity));
-    a.nq = nq;
-    a.n = n;
-    a.q_row0 = q_row0;
-    a.ld = ld;
-    a.d = (int)d;
-    a.k = k;
-    a.cap = topk_cap(k);
-    a.row_blocks = p.row_blocks;
-    a.splits = p.splits;
-    a.col_tiles = p.col_tiles;
-    a.min_similarity = min_similarity;
-    a.exclude_self = exclude_self;
-    a.gram = nullptr;
-    a.ldo = 0;
-    hipLaunchKernelGGL(cosine_tile_kernel<false>, dim3((unsigned)grid), dim3(TOPK_THREADS), p.lds_bytes,
-                       (hipStream_t)stream, a);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(topk_finalize_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const u64*>(workspace), nq, k, p.splits, out_idx, out_score, out_count);
-    HIP_TRY(hipGetLastError());
-    return TVBF_OK;
+    if (n < 1) return fail(TVBF_E_BAD_ARG, "bad n");
+    int rc = validate_accumulate(Zq, nq, q_row0, d, ld, Zall, n, 0, nullptr, 0, 0, k, min_similarity, workspace, 0,
+                                 max_merge_slots(k));
+    if (rc) return rc;
+    if (workspace_bytes < tvbf_topk_workspace_bytes(nq > 0 ? nq : 1, n, d, k))
+        return fail(TVBF_E_BAD_SHAPE, "workspace must be >= %zu bytes", tvbf_topk_workspace_bytes(nq > 0 ? nq : 1, n, d, k));
+    rc = tvbf_topk_begin(nq, k, min_similarity, workspace, workspace_bytes, stream);
+    if (rc) return rc;
+    int used = 0;
+    rc = tvbf_topk_accumulate_f32(Zq, nq, q_row0, d, ld, Zall, n, 0, nullptr, 0, 0, k, min_similarity, exclude_self,
+                                  workspace, workspace_bytes, 0, max_merge_slots(k), &used, stream);
+    if (rc) return rc;
+    return tvbf_topk_finish(nq, k, used, out_idx, out_score, out_count, workspace, workspace_bytes, stream);
 }
 
 int tvbf_gram_f32(const float* Zq, int64_t nq, const float* Zall, int64_t n, int64_t d, int64_t ld, float* out,
@@ -773,9 +880,9 @@ int tvbf_gram_f32(const float* Zq, int64_t nq, const float* Zall, int64_t n, int
     TopkArgs a;
     memset(&a, 0, sizeof(a));
     a.zq = Zq;
-    a.zall = Zall;
+    a.rng[0] = ColRange{Zall, n, 0, tiles_of(n)};
+    a.rng[1] = ColRange{Zall, 0, 0, 0};
     a.nq = nq;
-    a.n = n;
     a.ld = ld;
     a.d = (int)d;
     a.k = 0;

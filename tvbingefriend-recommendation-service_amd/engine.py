@@ -233,3 +233,85 @@ def dense_rows_topk(h: torch.Tensor, k: int, min_similarity: float, *, row0: int
                                           score.data_ptr(), count.data_ptr(), _stream_ptr())
     native.check(rc, "tvbf_dense_rows_topk_f64")
     return idx, score, count
+
+
+class TopkSession:
+    """Top-k of a block of query rows built up from column pieces.
+
+    begin -> accumulate(piece) ... -> finish.  A piece is one or two row ranges of
+    normalised features given as ``(tensor, n_rows, first_global_column)``; their
+    rows are the columns of the score matrix.  Every accumulate is one fused launch
+    on torch's current stream; lists of all pieces are merged by ``finish``.  The
+    result equals a single :func:`cosine_topk` over all columns, bit for bit.
+    """
+
+    def __init__(self, z_q: torch.Tensor, nq: int, q_row0: int, k: int, min_similarity: float, *,
+                 exclude_self: bool = True, slots: int = 32, workspace: torch.Tensor | None = None):
+        _require_cuda(z_q, "z_q")
+        if z_q.dim() != 2 or not z_q.is_contiguous() or nq > z_q.shape[0]:
+            raise ValueError("z_q must be a contiguous 2-D tensor with at least nq rows")
+        if not 1 <= k <= native.TVBF_MAX_K:
+            raise ValueError(f"k must be in 1..{native.TVBF_MAX_K}")
+        self.lib = native.load()
+        self.z_q, self.nq, self.q_row0, self.k = z_q, int(nq), int(q_row0), int(k)
+        self.min_similarity, self.exclude_self = float(min_similarity), bool(exclude_self)
+        self.ld = z_q.shape[1]
+        self.dev = z_q.device
+        self.slots = min(int(slots), int(self.lib.tvbf_topk_max_slots(k)))
+        need = int(self.lib.tvbf_topk_workspace_bytes_for_slots(max(self.nq, 1), k, self.slots))
+        if workspace is None:
+            workspace = torch.empty((need + 15) // 16 * 2, dtype=torch.int64, device=self.dev)
+        self.workspace = workspace
+        self.ws_bytes = workspace.numel() * workspace.element_size()
+        if self.ws_bytes < need:
+            raise ValueError(f"workspace holds {self.ws_bytes} bytes, {need} needed for {self.slots} slots")
+        self.used = 0
+        with torch.cuda.device(self.dev):
+            rc = self.lib.tvbf_topk_begin(self.nq, k, self.min_similarity, workspace.data_ptr(), self.ws_bytes,
+                                          _stream_ptr())
+        native.check(rc, "tvbf_topk_begin")
+
+    @staticmethod
+    def _range(r, ld):
+        if r is None:
+            return 0, 0, 0, None
+        t, n, col0 = r
+        n = int(n)
+        if n == 0:
+            return 0, 0, 0, None
+        _require_cuda(t, "column range")
+        if t.dim() != 2 or not t.is_contiguous() or t.shape[1] != ld or n > t.shape[0]:
+            raise ValueError("a column range must be a contiguous (rows >= n, ld) tensor")
+        return t.data_ptr(), n, int(col0), t
+
+    def accumulate(self, range_a, range_b=None, max_slots: int = 16) -> int:
+        pa, na, ca, keep_a = self._range(range_a, self.ld)
+        pb, nb, cb, keep_b = self._range(range_b, self.ld)
+        if na + nb == 0 or self.nq == 0:
+            return 0
+        budget = min(max_slots, self.slots - self.used)
+        if budget < 1:
+            raise ValueError("no partial-list slots left: create the session with more slots")
+        import ctypes
+
+        used = ctypes.c_int(0)
+        with torch.cuda.device(self.dev):
+            rc = self.lib.tvbf_topk_accumulate_f32(
+                self.z_q.data_ptr(), self.nq, self.q_row0, self.ld, self.ld, pa, na, ca, pb, nb, cb, self.k,
+                self.min_similarity, 1 if self.exclude_self else 0, self.workspace.data_ptr(), self.ws_bytes,
+                self.used, budget, ctypes.byref(used), _stream_ptr())
+        native.check(rc, "tvbf_topk_accumulate_f32")
+        self.used += used.value
+        return used.value
+
+    def finish(self, out: TopK | None = None) -> TopK:
+        if out is None:
+            out = TopK(torch.empty((self.nq, self.k), dtype=torch.int32, device=self.dev),
+                       torch.empty((self.nq, self.k), dtype=torch.float32, device=self.dev),
+                       torch.empty((self.nq,), dtype=torch.int32, device=self.dev))
+        with torch.cuda.device(self.dev):
+            rc = self.lib.tvbf_topk_finish(self.nq, self.k, self.used, out.idx.data_ptr(), out.score.data_ptr(),
+                                           out.count.data_ptr(), self.workspace.data_ptr(), self.ws_bytes,
+                                           _stream_ptr())
+        native.check(rc, "tvbf_topk_finish")
+        return out

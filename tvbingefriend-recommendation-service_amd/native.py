@@ -25,6 +25,11 @@ SYMBOLS = (
     "tvbf_normalize_blocks_f32",
     "tvbf_topk_workspace_bytes",
     "tvbf_cosine_topk_f32",
+    "tvbf_topk_max_slots",
+    "tvbf_topk_workspace_bytes_for_slots",
+    "tvbf_topk_begin",
+    "tvbf_topk_accumulate_f32",
+    "tvbf_topk_finish",
     "tvbf_gram_f32",
     "tvbf_component_scores_f32",
     "tvbf_weighted_sum3_f64",
@@ -104,6 +109,17 @@ def load() -> ctypes.CDLL:
     lib.tvbf_component_scores_f32.restype = c.c_int
     lib.tvbf_component_scores_f32.argtypes = [vp, i64, vp, i64, i64, c.POINTER(i32), c.POINTER(f32), c.c_int,
                                               vp, c.c_int, vp, vp]
+    lib.tvbf_topk_max_slots.restype = c.c_int
+    lib.tvbf_topk_max_slots.argtypes = [c.c_int]
+    lib.tvbf_topk_workspace_bytes_for_slots.restype = sz
+    lib.tvbf_topk_workspace_bytes_for_slots.argtypes = [i64, c.c_int, c.c_int]
+    lib.tvbf_topk_begin.restype = c.c_int
+    lib.tvbf_topk_begin.argtypes = [i64, c.c_int, f32, vp, sz, vp]
+    lib.tvbf_topk_accumulate_f32.restype = c.c_int
+    lib.tvbf_topk_accumulate_f32.argtypes = [vp, i64, i64, i64, i64, vp, i64, i64, vp, i64, i64, c.c_int, f32, c.c_int,
+                                             vp, sz, c.c_int, c.c_int, c.POINTER(c.c_int), vp]
+    lib.tvbf_topk_finish.restype = c.c_int
+    lib.tvbf_topk_finish.argtypes = [i64, c.c_int, c.c_int, vp, vp, vp, vp, sz, vp]
     lib.tvbf_gram_f32.restype = c.c_int
     lib.tvbf_gram_f32.argtypes = [vp, i64, vp, i64, i64, i64, vp, i64, vp]
     lib.tvbf_weighted_sum3_f64.restype = c.c_int

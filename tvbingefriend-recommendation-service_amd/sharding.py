@@ -68,22 +68,48 @@ def gather_lists(local: torch.Tensor, shard: Shard, group=None) -> torch.Tensor:
     return torch.cat(parts, dim=0)[: shard.n]
 
 
-def sharded_topk(x_shard: torch.Tensor, offsets, scales, shard: Shard, k: int, min_similarity: float,
-                 group=None, normalize_fn=None, topk_fn=None):
-    """normalise own rows -> all-gather -> top-K of own rows against all n columns.
+def column_pieces(shard: Shard):
+    """Column ranges a rank scores, in order: its own shard first (needs no communication), then
+    the columns after and before it (available once the all-gather has completed).
+    Each piece is (first_row_in_gathered_matrix, n_rows); rows of the gathered matrix are global
+    column indices, padding rows (>= n) are left out."""
+    own = (shard.row0, shard.rows)
+    after = (shard.row0 + shard.rows, max(0, shard.n - (shard.row0 + shard.rows)))
+    before = (0, shard.row0)
+    return own, after, before
 
-    ``x_shard`` holds this rank's rows padded to (per_rank, d).  ``normalize_fn`` and
-    ``topk_fn`` default to the HIP kernels; tests of the host logic inject CPU stand-ins.
+
+def sharded_topk(x_shard: torch.Tensor, offsets, scales, shard: Shard, k: int, min_similarity: float,
+                 group=None, normalize_fn=None, session_fn=None):
+    """normalise own rows -> all-gather (asynchronous) -> top-K of own rows against all n columns.
+
+    The rank first scores its rows against its own shard, which overlaps the collective, then
+    against the remaining columns; the pieces are merged on the device.  ``x_shard`` holds this
+    rank's rows padded to (per_rank, d).  ``normalize_fn(x, offsets, scales)`` and
+    ``session_fn(z_q, nq, q_row0, k, min_similarity)`` default to the HIP kernels
+    (engine.normalize_blocks / engine.TopkSession); tests of the host logic inject CPU stand-ins.
     Returns (TopK of the rank's ``shard.rows`` rows, z_all).
     """
-    if normalize_fn is None or topk_fn is None:
+    if normalize_fn is None or session_fn is None:
         from . import engine
 
         normalize_fn = normalize_fn or engine.normalize_blocks
-        topk_fn = topk_fn or engine.cosine_topk
+        session_fn = session_fn or engine.TopkSession
     if x_shard.shape[0] != shard.per_rank:
         raise ValueError("x_shard must be padded to per_rank rows")
     z_shard = normalize_fn(x_shard, offsets, scales)
-    z_all = all_gather_rows(z_shard, shard, group)
-    top = topk_fn(z_all, k, min_similarity, q_row0=shard.row0, nq=shard.rows, n=shard.n)
-    return top, z_all
+    if shard.world == 1:
+        session = session_fn(z_shard, shard.rows, 0, k, min_similarity)
+        session.accumulate((z_shard, shard.rows, 0))
+        return session.finish(), z_shard
+    z_all = torch.empty((shard.padded_total, z_shard.shape[1]), dtype=z_shard.dtype, device=z_shard.device)
+    if z_shard.is_cuda:
+        work = dist.all_gather_into_tensor(z_all, z_shard, group=group, async_op=True)
+    else:  # gloo: CPU tensors only
+        work = dist.all_gather(list(z_all.chunk(shard.world, dim=0)), z_shard, group=group, async_op=True)
+    own, after, before = column_pieces(shard)
+    session = session_fn(z_shard, shard.rows, shard.row0, k, min_similarity)
+    session.accumulate((z_shard, own[1], own[0]))            # runs while the shards travel
+    work.wait()                                              # the current stream now waits for the gather
+    session.accumulate((z_all[after[0]:], after[1], after[0]), (z_all, before[1], before[0]))
+    return session.finish(), z_all
