@@ -1,0 +1,33 @@
+"""Time the per-rank work of a row-sharded job on ONE GPU (no communication): the rank's own
+columns first, then the rest, as sharding.sharded_topk does.  usage: simulate_rank.py N D K WORLD RANK"""
+import sys, time
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import numpy as np, torch
+import tvbf_amd  # noqa
+from tvbingefriend_recommendation_service_amd import engine, sharding
+
+n, d, k, world, rank = (int(v) for v in sys.argv[1:6])
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev); g.manual_seed(1)
+x = torch.randn((n, d), generator=g, device=dev)
+z = engine.normalize_blocks(x, [0, d], [1.0])
+del x
+sh = sharding.shard_bounds(n, world, rank)
+own, after, before = sharding.column_pieces(sh)
+zq = z[sh.row0:sh.row0 + sh.rows].contiguous()
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+for it in range(4):
+    ev[0].record()
+    ses = engine.TopkSession(zq, sh.rows, sh.row0, k, -1.0)
+    s1 = ses.accumulate((zq, own[1], own[0]))
+    ev[1].record()
+    s2 = ses.accumulate((z[after[0]:], after[1], after[0]), (z, before[1], before[0]))
+    ev[2].record()
+    ses.finish()
+    ev[3].record()
+    torch.cuda.synchronize()
+t = [ev[i].elapsed_time(ev[i + 1]) for i in range(3)]
+flops = 2.0 * sh.rows * n * d
+print(f"rank {rank}/{world}: rows {sh.rows}  own {t[0]:.2f} ms ({s1} splits)  rest {t[1]:.2f} ms ({s2} splits)  merge {t[2]:.2f} ms"
+      f"  total {sum(t):.2f} ms  {flops / sum(t) / 1e9:.1f} TFLOP/s")
