@@ -67,6 +67,48 @@ int tvbf_normalize_blocks_f32(const float* X, int64_t n, int64_t d, int64_t ldx,
                               float* Z, int64_t ldz, void* stream);
 
 /*
+ * K1 fed from the reference's on-disk arrays instead of one packed fp32 matrix:
+ * gathers up to TVBF_MAX_SOURCES dense or CSR sources into the columns of a row,
+ * then normalises and weights block-wise exactly as tvbf_normalize_blocks_f32
+ * (bit-identical Z for the same values).  Replaces the host-side densification
+ * that sklearn's cosine_similarity performs on the TF-IDF CSR matrix
+ * (ml/similarity_computer.py:58; file contract scripts/compute_features.py:115-129:
+ * genre int64, text CSR float64, platform float64, type bool, language float64)
+ * and np.hstack of the metadata blocks (ml/similarity_computer.py:84).
+ *
+ *   sources        host array of ns descriptors; the pointers inside are device pointers
+ *     kind         TVBF_SRC_DENSE_* : data = n x width elements, row stride ld elements
+ *                  TVBF_SRC_CSR_*   : indptr (n+1), indices (nnz), data (nnz); index64 != 0
+ *                                     when indptr / indices are int64 (else int32)
+ *     z_col, width the source fills columns [z_col, z_col + width) of the row;
+ *                  CSR entries outside [0, width) are ignored, repeated entries add up
+ *   block_offsets / block_scales / nb / d / Z / ldz   as in tvbf_normalize_blocks_f32;
+ *                  columns not covered by any source are zero; ldz * 4 bytes <= 160 KiB
+ */
+#define TVBF_MAX_SOURCES 8
+#define TVBF_SRC_DENSE_F32 0
+#define TVBF_SRC_DENSE_F64 1
+#define TVBF_SRC_DENSE_I64 2
+#define TVBF_SRC_DENSE_U8 3 /* bool bytes: non-zero = 1 */
+#define TVBF_SRC_CSR_F32 4
+#define TVBF_SRC_CSR_F64 5
+
+typedef struct tvbf_source {
+    int32_t kind;
+    int32_t index64;
+    int32_t width;
+    int32_t z_col;
+    const void* data;
+    int64_t ld;
+    const void* indptr;
+    const void* indices;
+} tvbf_source;
+
+int tvbf_assemble_normalize_f32(const tvbf_source* sources, int ns, int64_t n, int64_t d,
+                                const int32_t* block_offsets, const float* block_scales, int nb,
+                                float* Z, int64_t ldz, void* stream);
+
+/*
  * Bytes of device workspace tvbf_cosine_topk_f32 needs for these sizes on the
  * current device.  Never fails for valid sizes; returns 0 for invalid ones.
  */

@@ -224,3 +224,32 @@ def test_sharded_topk_two_ranks_gloo(pkg, n):
 
     check_topk_against_scores(z @ z.T, 0, k, min_sim, ret["idx"], ret["score"], ret["count"], tol=1e-9,
                               what=f"gloo shards n={n}", check_tie_order=False)
+
+
+def test_block_sources_match_packed_layout(pkg):
+    """The stored-form sources (CSR text, int64 genre, bool type) describe exactly the matrix
+    that pack_features builds on the host, for both variants."""
+    from synth import hybrid_like_blocks
+    from tvbingefriend_recommendation_service_amd import features as feat
+
+    f = hybrid_like_blocks(64, 3, d_text=61, as_features=True)
+    for variant in ("computer", "populate"):
+        x, layout = feat.pack_features(f, 0.4, 0.5, 0.1, variant)
+        sources, layout2 = feat.block_sources(f, 0.4, 0.5, 0.1, variant)
+        assert (layout2.offsets, layout2.widths, layout2.weights, layout2.groups) == \
+               (layout.offsets, layout.widths, layout.weights, layout.groups)
+        y = np.zeros_like(x)
+        kinds = []
+        for s in sources:
+            if s[0] == "dense":
+                y[:, s[2]:s[2] + s[1].shape[1]] = s[1]
+                kinds.append(s[1].dtype)
+            else:
+                _, indptr, indices, data, width, zc = s
+                for i in range(64):
+                    y[i, zc + indices[indptr[i]:indptr[i + 1]]] = data[indptr[i]:indptr[i + 1]]
+                kinds.append("csr")
+        assert np.array_equal(x, y)
+        assert kinds == [np.int64, "csr", np.float64, np.bool_, np.float64]  # nothing converted on the host
+    with pytest.raises(KeyError):
+        feat.block_sources({"genre_features": f["genre_features"]}, 0.4, 0.5, 0.1)

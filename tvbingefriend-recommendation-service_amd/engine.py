@@ -20,7 +20,7 @@ LD_ALIGN = 32  # Z rows are padded to a multiple of one k-tile (32 floats = 128 
 def _require_cuda(t: torch.Tensor, name: str, dtype=torch.float32) -> None:
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise native.NativeLibraryError(f"{name} must be a tensor on the GPU (there is no CPU path)")
-    if t.dtype != dtype:
+    if dtype is not None and t.dtype != dtype:
         raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
 
 
@@ -56,6 +56,82 @@ def normalize_blocks(x: torch.Tensor, offsets, scales, out: torch.Tensor | None 
         rc = lib.tvbf_normalize_blocks_f32(x.data_ptr(), n, d, x.stride(0), off, sc, nb,
                                            out.data_ptr(), ld, _stream_ptr())
     native.check(rc, "tvbf_normalize_blocks_f32")
+    return out
+
+
+@dataclass
+class DenseSource:
+    """A dense (n, width) block on the device: fp32, fp64, int64, bool or uint8."""
+
+    data: torch.Tensor
+    z_col: int
+
+
+@dataclass
+class CsrSource:
+    """A CSR block on the device: indptr (n+1), indices (nnz) both int32 or both int64,
+    data (nnz) fp32 or fp64; ``width`` columns."""
+
+    indptr: torch.Tensor
+    indices: torch.Tensor
+    data: torch.Tensor
+    width: int
+    z_col: int
+
+
+_DENSE_KINDS = {torch.float32: native.SRC_DENSE_F32, torch.float64: native.SRC_DENSE_F64,
+                torch.int64: native.SRC_DENSE_I64, torch.bool: native.SRC_DENSE_U8,
+                torch.uint8: native.SRC_DENSE_U8}
+
+
+def assemble_normalize(sources, n: int, offsets, scales, out: torch.Tensor | None = None) -> torch.Tensor:
+    """Z (n, ld) from feature blocks that are already on the device in their stored form
+    (dense arrays and CSR triples), normalised and weighted block-wise like
+    :func:`normalize_blocks`; no dense copy of a sparse block is ever made."""
+    if not 1 <= len(sources) <= native.TVBF_MAX_SOURCES:
+        raise ValueError(f"1..{native.TVBF_MAX_SOURCES} sources are supported")
+    d = int(offsets[-1])
+    ld = padded_ld(d)
+    arr = (native.Source * len(sources))()
+    device = None
+    for i, s in enumerate(sources):
+        if isinstance(s, DenseSource):
+            t = s.data
+            _require_cuda(t, "dense source", None)
+            if t.dim() != 2 or t.shape[0] != n or (t.shape[1] > 1 and t.stride(1) != 1):
+                raise ValueError("dense sources must be (n, width) with contiguous rows")
+            if t.dtype not in _DENSE_KINDS:
+                raise TypeError(f"unsupported dense source dtype {t.dtype}")
+            arr[i] = native.Source(_DENSE_KINDS[t.dtype], 0, t.shape[1], int(s.z_col), t.data_ptr() or None,
+                                   t.stride(0) if t.shape[0] > 1 else t.shape[1], None, None)
+            device = t.device
+        elif isinstance(s, CsrSource):
+            for t, name in ((s.indptr, "indptr"), (s.indices, "indices"), (s.data, "data")):
+                _require_cuda(t, name, None)
+                if t.dim() != 1 or not t.is_contiguous():
+                    raise ValueError(f"CSR {name} must be a contiguous vector")
+            if s.indptr.numel() != n + 1 or s.indices.numel() != s.data.numel():
+                raise ValueError("CSR arrays have inconsistent lengths")
+            if s.indptr.dtype != s.indices.dtype or s.indptr.dtype not in (torch.int32, torch.int64):
+                raise TypeError("CSR indptr / indices must both be int32 or both int64")
+            if s.data.dtype not in (torch.float32, torch.float64):
+                raise TypeError("CSR data must be fp32 or fp64")
+            kind = native.SRC_CSR_F32 if s.data.dtype == torch.float32 else native.SRC_CSR_F64
+            arr[i] = native.Source(kind, int(s.indptr.dtype == torch.int64), int(s.width), int(s.z_col),
+                                   s.data.data_ptr() or None, 0, s.indptr.data_ptr(), s.indices.data_ptr() or None)
+            device = s.indptr.device
+        else:
+            raise TypeError("sources must be DenseSource or CsrSource")
+    if out is None:
+        out = torch.empty((n, ld), dtype=torch.float32, device=device)
+    _require_cuda(out, "out")
+    if out.shape != (n, ld) or not out.is_contiguous():
+        raise ValueError(f"out must be a contiguous ({n}, {ld}) tensor")
+    off, sc, nb = native.block_arrays(offsets, scales)
+    lib = native.load()
+    with torch.cuda.device(out.device):
+        rc = lib.tvbf_assemble_normalize_f32(arr, len(sources), n, d, off, sc, nb, out.data_ptr(), ld, _stream_ptr())
+    native.check(rc, "tvbf_assemble_normalize_f32")
     return out
 
 

@@ -123,6 +123,74 @@ def pack_features(features: dict, genre_weight: float, text_weight: float, metad
     raise ValueError(f"unknown variant {variant!r}")
 
 
+def _is_sparse(x) -> bool:
+    return hasattr(x, "toarray") and hasattr(x, "tocsr")
+
+
+def block_sources(features: dict, genre_weight: float, text_weight: float, metadata_weight: float,
+                  variant: str = "computer"):
+    """The five feature arrays in their stored form plus the column each one starts at.
+
+    Same layout as :func:`pack_features` (so both routes produce the same Z), but nothing is
+    densified or converted on the host: a SciPy sparse block stays a CSR triple, dense blocks
+    keep their dtype (int64 genre, bool type, float64 one-hots; anything else becomes fp32).
+    Returns (sources, layout); a source is ("dense", array, z_col) or
+    ("csr", indptr, indices, data, width, z_col).
+    """
+    missing = [k for k in FEATURE_KEYS if k not in features]
+    if missing:
+        raise KeyError(missing[0])
+    names = ("genre_features", "text_features", "platform_features", "type_features", "language_features")
+    arrays = []
+    for name in names:
+        a = features[name]
+        if _is_sparse(a):
+            a = a.tocsr()
+            if not a.has_canonical_format:
+                a = a.copy()
+                a.sum_duplicates()
+        else:
+            a = np.asarray(a)
+            if a.ndim != 2:
+                raise ValueError(f"feature blocks must be 2-D, got shape {a.shape}")
+            if a.dtype not in (np.float32, np.float64, np.int64, np.bool_, np.uint8):
+                a = a.astype(np.float32)
+            a = np.ascontiguousarray(a)
+        arrays.append(a)
+    n = arrays[0].shape[0]
+    if any(a.shape[0] != n for a in arrays):
+        raise ValueError("all feature blocks must have the same number of rows")
+    widths = [a.shape[1] for a in arrays]
+    pad = lambda w: (w + BLOCK_ALIGN - 1) // BLOCK_ALIGN * BLOCK_ALIGN  # noqa: E731
+    if variant == "computer":
+        total = genre_weight + text_weight + metadata_weight
+        weights = [genre_weight / total, text_weight / total, metadata_weight / total]
+        meta_w = widths[2] + widths[3] + widths[4]
+        offsets = [0, pad(widths[0])]
+        offsets.append(offsets[-1] + pad(widths[1]))
+        offsets.append(offsets[-1] + pad(meta_w))
+        z_cols = [0, offsets[1], offsets[2], offsets[2] + widths[2], offsets[2] + widths[2] + widths[3]]
+        layout = BlockLayout(offsets, [widths[0], widths[1], meta_w], weights, [0, 1, 2])
+    elif variant == "populate":
+        weights = [genre_weight, text_weight, metadata_weight / 3, metadata_weight / 3, metadata_weight / 3]
+        offsets = [0]
+        for w in widths:
+            offsets.append(offsets[-1] + pad(w))
+        z_cols = offsets[:-1]
+        layout = BlockLayout(offsets, widths, weights, [0, 1, 2, 2, 2])
+    else:
+        raise ValueError(f"unknown variant {variant!r}")
+    if layout.offsets[-1] == 0:
+        layout.offsets[-1] = BLOCK_ALIGN
+    sources = []
+    for a, zc in zip(arrays, z_cols):
+        if _is_sparse(a):
+            sources.append(("csr", a.indptr, a.indices, a.data, a.shape[1], zc))
+        else:
+            sources.append(("dense", a, zc))
+    return sources, layout
+
+
 def fold_components(comp: np.ndarray, layout: BlockLayout) -> np.ndarray:
     """(nq, k, nb) per-block cosines -> (nq, k, 3) genre / text / metadata scores
     (metadata = mean of its blocks, scripts/populate_database.py:187)."""

@@ -185,14 +185,23 @@ class SimilarityComputer:
         from .. import engine
 
         dev = _torch_device(self.device)
-        x, layout = feat.pack_features(features, self.genre_weight, self.text_weight,
-                                       self.metadata_weight, variant)
-        xd = torch.from_numpy(x).to(dev)
+        # the stored arrays go to the device as they are (CSR text stays CSR); Z is built there
+        sources, layout = feat.block_sources(features, self.genre_weight, self.text_weight,
+                                             self.metadata_weight, variant)
+        dev_sources = []
+        for src in sources:
+            if src[0] == "dense":
+                dev_sources.append(engine.DenseSource(torch.from_numpy(src[1]).to(dev), src[2]))
+            else:
+                _, indptr, indices, data, width, z_col = src
+                dev_sources.append(engine.CsrSource(torch.from_numpy(indptr).to(dev), torch.from_numpy(indices).to(dev),
+                                                    torch.from_numpy(data).to(dev), width, z_col))
+        n = int(sources[0][1].shape[0]) - (1 if sources[0][0] == "csr" else 0)
         scales = layout.scales()
-        z = engine.normalize_blocks(xd, layout.offsets, scales)
+        z = engine.assemble_normalize(dev_sources, n, layout.offsets, scales)
         top = engine.cosine_topk(z, k, min_similarity)
         cscales = layout.component_scales()
-        zc = z if cscales == scales else engine.normalize_blocks(xd, layout.offsets, cscales)
+        zc = z if cscales == scales else engine.assemble_normalize(dev_sources, n, layout.offsets, cscales)
         comp = engine.component_scores(zc, layout.offsets, cscales, top.idx)
         return TopKResult(top.idx.cpu().numpy(), top.score.cpu().numpy(), top.count.cpu().numpy(),
                           feat.fold_components(comp.cpu().numpy(), layout))

@@ -16,13 +16,14 @@ CSRC = Path(__file__).resolve().parent / "csrc"
 INCLUDE = Path(__file__).resolve().parent.parent / "include"
 # TVBF_LIB selects another build of the same ABI (timing-only diagnostic variants under build/)
 LIB_PATH = Path(os.environ["TVBF_LIB"]) if os.environ.get("TVBF_LIB") else CSRC / "libtvbf.so"
-SOURCES = [CSRC / "tvbf_kernels.hip", CSRC / "tvbf_stats.hip"]
+SOURCES = [CSRC / "tvbf_kernels.hip", CSRC / "tvbf_stats.hip", CSRC / "tvbf_assemble.hip"]
 
 # Every symbol include/tvbf.h declares.
 SYMBOLS = (
     "tvbf_version",
     "tvbf_last_error",
     "tvbf_normalize_blocks_f32",
+    "tvbf_assemble_normalize_f32",
     "tvbf_topk_workspace_bytes",
     "tvbf_cosine_topk_f32",
     "tvbf_topk_max_slots",
@@ -40,6 +41,16 @@ SYMBOLS = (
 
 TVBF_MAX_BLOCKS = 8
 TVBF_MAX_K = 100
+TVBF_MAX_SOURCES = 8
+SRC_DENSE_F32, SRC_DENSE_F64, SRC_DENSE_I64, SRC_DENSE_U8, SRC_CSR_F32, SRC_CSR_F64 = range(6)
+
+
+class Source(ctypes.Structure):
+    """struct tvbf_source of include/tvbf.h."""
+
+    _fields_ = [("kind", ctypes.c_int32), ("index64", ctypes.c_int32), ("width", ctypes.c_int32),
+                ("z_col", ctypes.c_int32), ("data", ctypes.c_void_p), ("ld", ctypes.c_int64),
+                ("indptr", ctypes.c_void_p), ("indices", ctypes.c_void_p)]
 
 
 class NativeLibraryError(RuntimeError):
@@ -101,6 +112,9 @@ def load() -> ctypes.CDLL:
     lib.tvbf_normalize_blocks_f32.restype = c.c_int
     lib.tvbf_normalize_blocks_f32.argtypes = [vp, i64, i64, i64, c.POINTER(i32), c.POINTER(f32), c.c_int,
                                               vp, i64, vp]
+    lib.tvbf_assemble_normalize_f32.restype = c.c_int
+    lib.tvbf_assemble_normalize_f32.argtypes = [c.POINTER(Source), c.c_int, i64, i64, c.POINTER(i32), c.POINTER(f32),
+                                                c.c_int, vp, i64, vp]
     lib.tvbf_topk_workspace_bytes.restype = sz
     lib.tvbf_topk_workspace_bytes.argtypes = [i64, i64, i64, c.c_int]
     lib.tvbf_cosine_topk_f32.restype = c.c_int
