@@ -242,6 +242,28 @@ int tvbf_dense_rows_topk_f64(const double* H, int64_t n_rows, int64_t n_cols, in
                              int k, double min_similarity, int exclude_self, int32_t* out_idx,
                              double* out_score, int32_t* out_count, void* stream);
 
+/*
+ * Ad-hoc neighbours of a few query vectors against all n rows: one pass over Z
+ * (memory-bound), scores to the workspace, selection, merge.  Replaces the single-show
+ * lookup of services/content_based_service.py:161-236 (row of the hybrid matrix,
+ * descending argsort :209, skip self :214-215, stop below min_similarity :220-221,
+ * stop at n :233-234) without a stored n x n matrix; other weights than the ones Z
+ * was built with are applied by re-scaling the blocks of the query vector only.
+ *
+ *   Zq          device, nq x d fp32, row stride ldq (any vectors, not only rows of Zall)
+ *   self_index  host, nq column indices to leave out (-1: none), or NULL
+ *   Zall        device, n x d fp32, row stride ld; d a multiple of 4, at most 16384
+ *   outputs     as tvbf_cosine_topk_f32 (scores are plain fp32 dot products; they may
+ *               differ from the fused kernel's in the last bits: another summation order)
+ *   workspace   device, >= tvbf_query_workspace_bytes(nq, n, k) bytes, 16-byte aligned
+ */
+#define TVBF_MAX_QUERIES 64
+size_t tvbf_query_workspace_bytes(int64_t nq, int64_t n, int k);
+int tvbf_query_topk_f32(const float* Zq, int64_t nq, int64_t ldq, const int64_t* self_index,
+                        const float* Zall, int64_t n, int64_t d, int64_t ld, int k,
+                        float min_similarity, int32_t* out_idx, float* out_score,
+                        int32_t* out_count, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -261,3 +261,45 @@ def test_service_matrix_path(pkg, device, tmp_path):
                                              order_fn=so.deterministic_order)
         ref = [{("similar_show_id" if k == "show_id" else k): v for k, v in r.items()} for r in ref]
         assert sink.records.get(sid, []) == ref
+
+
+def test_service_feature_path_matches_matrix_semantics(pkg, device, tmp_path):
+    """get_recommendations_from_features: same records as the matrix lookup (scores within the
+    fp32 tolerance), also with per-call weights; no matrix files are needed."""
+    from parity import SCORE_TOL
+    from tvbingefriend_recommendation_service_amd.services.content_based_service import (
+        ContentBasedRecommendationService,
+    )
+
+    g = load_golden("plumbing_100")
+    feats = _write_feature_dir(tmp_path, g)
+    o = so.SimilarityComputerOracle().compute_all_similarities(feats)
+    ids = g["ids"].tolist()
+    svc = ContentBasedRecommendationService(tmp_path, 0.4, 0.5, 0.1)
+    for weights in (None, (1.0, 1.0, 2.0), (0.0, 1.0, 0.0)):
+        gw, tw, mw = weights or (0.4, 0.5, 0.1)
+        hyb = so.service_hybrid(o["genre_similarity"], o["text_similarity"], o["metadata_similarity"], gw, tw, mw)
+        for sid in ids[:30]:
+            for n_, ms in ((10, 0.0), (5, 0.3), (0, 0.0)):
+                kw = {} if weights is None else dict(genre_weight=gw, text_weight=tw, metadata_weight=mw)
+                got = svc.get_recommendations_from_features(sid, n=n_, min_similarity=ms, **kw)
+                ref = so.recommendations_from_matrix(sid, ids, hyb, o["genre_similarity"], o["text_similarity"],
+                                                     o["metadata_similarity"], n=n_, min_similarity=ms,
+                                                     order_fn=so.deterministic_order)
+                row = ids.index(sid)
+                # ranks whose neighbours are further than the tolerance apart must agree exactly
+                ref_scores = [r["similarity_score"] for r in ref]
+                assert abs(len(got) - len(ref)) <= 1, (sid, n_, ms)
+                for s_, (a, b) in enumerate(zip(got, ref)):
+                    assert abs(a["similarity_score"] - b["similarity_score"]) <= SCORE_TOL
+                    clear = all(abs(ref_scores[s_] - x) > 2 * SCORE_TOL for i_, x in enumerate(ref_scores) if i_ != s_)
+                    last = s_ == len(ref) - 1  # the first left-out neighbour may tie with the last kept one
+                    if clear and not last:
+                        assert a["show_id"] == b["show_id"], (sid, n_, ms, s_)
+                    j = ids.index(a["show_id"])
+                    assert abs(a["similarity_score"] - hyb[row, j]) <= SCORE_TOL
+                    assert abs(a["genre_score"] - o["genre_similarity"][row, j]) <= SCORE_TOL
+                    assert abs(a["text_score"] - o["text_similarity"][row, j]) <= SCORE_TOL
+                    assert abs(a["metadata_score"] - o["metadata_similarity"][row, j]) <= SCORE_TOL
+                    assert a["show_id"] != sid
+    assert svc.get_recommendations_from_features(-5) == []

@@ -600,6 +600,130 @@ __global__ __launch_bounds__(256) void component_scores_kernel(const float* __re
 }
 
 // --------------------------------------------------------------------------
+// Ad-hoc queries: a few query vectors against every row of Z (HBM-bound).
+//
+// query_scores_kernel: Z is read once; the queries sit in LDS; a wavefront takes
+// four rows at a time, lanes split the columns (one 16-byte chunk per 256 columns),
+// 4 x NQ partial dot products are reduced across the wave.
+// query_select_kernel: one wavefront per (query, column range) runs the same
+// append / compact selection as the fused kernel over the stored scores and emits
+// a partial list in the layout topk_finalize_kernel merges.
+// --------------------------------------------------------------------------
+constexpr int QUERY_MAX_FLOATS = 16384;  // NQ * d floats of LDS per launch (64 KiB)
+constexpr int QUERY_ROWS = 4;            // rows per wavefront and iteration
+constexpr int QUERY_CAP = 128;           // candidate buffer of one selection wave
+
+template <int NQ>
+__global__ __launch_bounds__(256) void query_scores_kernel(const float* __restrict__ zq, int nq, int64_t ldq,
+                                                           const float* __restrict__ z, int64_t n, int d,
+                                                           int64_t ld, float* __restrict__ scores) {
+    extern __shared__ __attribute__((aligned(16))) float qv[];  // [NQ][d], rows >= nq are zero
+    for (int i = threadIdx.x; i < NQ * d; i += 256) {
+        const int q = i / d, c = i - q * d;
+        qv[i] = q < nq ? zq[q * ldq + c] : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t stride = (int64_t)gridDim.x * 4 * QUERY_ROWS;
+    for (int64_t r0 = wave * QUERY_ROWS; r0 < n; r0 += stride) {
+        float acc[QUERY_ROWS][NQ];
+#pragma unroll
+        for (int r = 0; r < QUERY_ROWS; ++r)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc[r][q] = 0.f;
+        const float* rows[QUERY_ROWS];
+#pragma unroll
+        for (int r = 0; r < QUERY_ROWS; ++r) rows[r] = z + (r0 + r < n ? r0 + r : n - 1) * ld;
+        for (int c = 4 * lane; c < d; c += 256) {
+            f32x4 zr[QUERY_ROWS];
+#pragma unroll
+            for (int r = 0; r < QUERY_ROWS; ++r) zr[r] = *reinterpret_cast<const f32x4*>(rows[r] + c);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const f32x4 qq = *reinterpret_cast<const f32x4*>(qv + q * d + c);
+#pragma unroll
+                for (int r = 0; r < QUERY_ROWS; ++r) {
+                    acc[r][q] = fmaf(zr[r][0], qq[0], acc[r][q]);
+                    acc[r][q] = fmaf(zr[r][1], qq[1], acc[r][q]);
+                    acc[r][q] = fmaf(zr[r][2], qq[2], acc[r][q]);
+                    acc[r][q] = fmaf(zr[r][3], qq[3], acc[r][q]);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            float mine = 0.f;  // lane r keeps the score of row r0 + r
+#pragma unroll
+            for (int r = 0; r < QUERY_ROWS; ++r) {
+                const float v = wave_sum(acc[r][q]);
+                mine = lane == r ? v : mine;
+            }
+            if (q < nq && lane < QUERY_ROWS && r0 + lane < n) scores[(int64_t)q * n + r0 + lane] = mine;
+        }
+    }
+}
+
+struct QuerySelf {
+    int64_t col[8];  // column excluded for query q (-1: none)
+};
+
+__global__ __launch_bounds__(256) void query_select_kernel(const float* __restrict__ scores, int64_t n, int nq,
+                                                           QuerySelf self, int k, float min_similarity, int lists,
+                                                           u64* __restrict__ partial) {
+    __shared__ u64 buf_all[4][QUERY_CAP];
+    __shared__ u64 mkey_all[4];
+    __shared__ unsigned cnt_all[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int list = blockIdx.x * 4 + wave;
+    const int q = blockIdx.y;
+    if (list >= lists) return;  // wave-private state only: no workgroup barrier below
+    u64* buf = buf_all[wave];
+    if (lane == 0) {
+        mkey_all[wave] = sentinel_key(min_similarity);
+        cnt_all[wave] = 0u;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    u64 mkey = sentinel_key(min_similarity);
+    float thr = min_similarity;
+    const int64_t begin = n * list / lists, end = n * (list + 1) / lists;
+    const float* s = scores + (int64_t)q * n;
+    const int64_t skip = self.col[q];
+#pragma nounroll
+    for (int64_t c0 = begin; c0 < end; c0 += 64) {
+        const int64_t c = c0 + lane;
+        const float v = c < end ? s[c] : -INFINITY;
+        const u64 key = make_key(v, (int)c);
+        bool cand = c < end && c != skip && v >= thr && key > mkey;
+#pragma nounroll
+        while (__any(cand)) {
+            if (cand) {
+                const unsigned pos = atomicAdd(&cnt_all[wave], 1u);
+                if (pos < (unsigned)QUERY_CAP) {
+                    buf[pos] = key;
+                    cand = false;
+                }
+            }
+            if (__any(cand)) {  // buffer full: keep the k best, raise the threshold, retry the rest
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                compact_row(buf, &cnt_all[wave], &mkey_all[wave], k, QUERY_CAP, lane, nullptr);
+                mkey = mkey_all[wave];
+                thr = fmaxf(ordered_to_f32((uint32_t)(mkey >> 32)), min_similarity);
+                cand = cand && v >= thr && key > mkey;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    compact_row(buf, &cnt_all[wave], &mkey_all[wave], k, QUERY_CAP, lane, nullptr);
+    const int have = (int)cnt_all[wave];
+    u64* dst = partial + ((int64_t)list * nq + q) * k;
+    for (int i = lane; i < k; i += 64) dst[i] = i < have ? buf[i] : sentinel_key(min_similarity);
+}
+
+// --------------------------------------------------------------------------
 // host side
 // --------------------------------------------------------------------------
 struct Plan {
@@ -696,6 +820,15 @@ static int fill_blocks(BlockDesc* bd, const int32_t* off, const float* scale, in
     }
     for (int b = 0; b < nb; ++b) bd->scale[b] = scale[b];
     return TVBF_OK;
+}
+
+template <int NQ>
+static void launch_query_scores(const float* zq, int nq, int64_t ldq, const float* z, int64_t n, int d, int64_t ld,
+                                float* scores, int cus, hipStream_t stream) {
+    int64_t grid = (n + 4 * QUERY_ROWS - 1) / (4 * QUERY_ROWS);
+    if (grid > (int64_t)cus * 8) grid = (int64_t)cus * 8;
+    hipLaunchKernelGGL(query_scores_kernel<NQ>, dim3((unsigned)grid), dim3(256), (size_t)NQ * d * sizeof(float), stream,
+                       zq, nq, ldq, z, n, d, ld, scores);
 }
 
 extern "C" {
@@ -864,6 +997,79 @@ int tvbf_cosine_topk_f32(const float* Zq, int64_t nq, int64_t q_row0, const floa
                                   workspace, workspace_bytes, 0, max_merge_slots(k), &used, stream);
     if (rc) return rc;
     return tvbf_topk_finish(nq, k, used, out_idx, out_score, out_count, workspace, workspace_bytes, stream);
+}
+
+// Partial lists per query: every selection wave should see a few thousand scores.
+static int query_lists(int64_t n, int k) {
+    int64_t lists = (n + 4095) / 4096;
+    const int cap = max_merge_slots(k);
+    if (lists > cap) lists = cap;
+    if (lists < 1) lists = 1;
+    return (int)lists;
+}
+
+size_t tvbf_query_workspace_bytes(int64_t nq, int64_t n, int k) {
+    if (nq < 1 || nq > TVBF_MAX_QUERIES || n < 1 || k < 1 || k > TVBF_MAX_K) return 0;
+    const size_t lists_bytes = ws_bound_bytes(nq) + (size_t)query_lists(n, k) * ws_slot_bytes(nq, k);
+    return (lists_bytes + 15) / 16 * 16 + (size_t)nq * (size_t)n * sizeof(float);
+}
+
+int tvbf_query_topk_f32(const float* Zq, int64_t nq, int64_t ldq, const int64_t* self_index, const float* Zall,
+                        int64_t n, int64_t d, int64_t ld, int k, float min_similarity, int32_t* out_idx,
+                        float* out_score, int32_t* out_count, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_topk_common(nq, k, workspace);
+    if (rc) return rc;
+    if (!Zq || !Zall || !out_idx || !out_score || !out_count) return fail(TVBF_E_BAD_ARG, "null pointer argument");
+    if (nq < 1 || nq > TVBF_MAX_QUERIES) return fail(TVBF_E_BAD_ARG, "nq must be 1..%d", TVBF_MAX_QUERIES);
+    if (n < 1 || n > INT32_MAX - 64) return fail(TVBF_E_BAD_ARG, "bad n");
+    if (d < 1 || d > QUERY_MAX_FLOATS || (d & 3)) return fail(TVBF_E_BAD_SHAPE, "d must be a multiple of 4, at most %d", QUERY_MAX_FLOATS);
+    if ((ld & 3) || ld < d || (ldq & 3) || ldq < d) return fail(TVBF_E_BAD_SHAPE, "ld and ldq must be multiples of 4, >= d");
+    if (((uintptr_t)Zq & 15) || ((uintptr_t)Zall & 15)) return fail(TVBF_E_BAD_SHAPE, "Z must be 16-byte aligned");
+    if (min_similarity != min_similarity) return fail(TVBF_E_BAD_ARG, "min_similarity is NaN");
+    if (min_similarity < -FLT_MAX) min_similarity = -FLT_MAX;
+    const size_t need = tvbf_query_workspace_bytes(nq, n, k);
+    if (workspace_bytes < need) return fail(TVBF_E_BAD_SHAPE, "workspace must be >= %zu bytes", need);
+    const int lists = query_lists(n, k);
+    char* ws = reinterpret_cast<char*>(workspace);
+    const size_t lists_bytes = (ws_bound_bytes(nq) + (size_t)lists * ws_slot_bytes(nq, k) + 15) / 16 * 16;
+    float* scores = reinterpret_cast<float*>(ws + lists_bytes);
+    u64* partial = reinterpret_cast<u64*>(ws + ws_bound_bytes(nq));
+    const int cus = device_cus();
+    hipStream_t st = (hipStream_t)stream;
+
+    // queries per launch: as many as fit the LDS budget, rounded down to 8 / 4 / 2 / 1
+    int per = (int)(QUERY_MAX_FLOATS / d);
+    per = per >= 8 ? 8 : per >= 4 ? 4 : per >= 2 ? 2 : 1;
+    if ((size_t)per * d * sizeof(float) > 48 * 1024) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(query_scores_kernel<8>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, QUERY_MAX_FLOATS * 4));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(query_scores_kernel<4>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, QUERY_MAX_FLOATS * 4));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(query_scores_kernel<2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, QUERY_MAX_FLOATS * 4));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(query_scores_kernel<1>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, QUERY_MAX_FLOATS * 4));
+    }
+    for (int64_t q0 = 0; q0 < nq; q0 += per) {
+        const int m = (int)(nq - q0 < per ? nq - q0 : per);
+        const float* zq = Zq + q0 * ldq;
+        float* sc = scores + q0 * n;
+        if (m > 4) launch_query_scores<8>(zq, m, ldq, Zall, n, (int)d, ld, sc, cus, st);
+        else if (m > 2) launch_query_scores<4>(zq, m, ldq, Zall, n, (int)d, ld, sc, cus, st);
+        else if (m > 1) launch_query_scores<2>(zq, m, ldq, Zall, n, (int)d, ld, sc, cus, st);
+        else launch_query_scores<1>(zq, m, ldq, Zall, n, (int)d, ld, sc, cus, st);
+        HIP_TRY(hipGetLastError());
+    }
+    for (int64_t q0 = 0; q0 < nq; q0 += 8) {
+        const int m = (int)(nq - q0 < 8 ? nq - q0 : 8);
+        QuerySelf self;
+        for (int i = 0; i < 8; ++i) self.col[i] = (self_index && i < m) ? self_index[q0 + i] : -1;
+        // the kernel indexes lists as [list][query of the whole call]: pass the offset base
+        hipLaunchKernelGGL(query_select_kernel, dim3((unsigned)((lists + 3) / 4), (unsigned)m), dim3(256), 0, st,
+                           scores + q0 * n, n, (int)nq, self, k, min_similarity, lists, partial + q0 * k);
+        HIP_TRY(hipGetLastError());
+    }
+    return tvbf_topk_finish(nq, k, lists, out_idx, out_score, out_count, workspace, workspace_bytes, stream);
 }
 
 int tvbf_gram_f32(const float* Zq, int64_t nq, const float* Zall, int64_t n, int64_t d, int64_t ld, float* out,

@@ -8,6 +8,7 @@ returns without synchronising.
 
 from __future__ import annotations
 
+import ctypes
 from dataclasses import dataclass
 
 import torch
@@ -309,6 +310,49 @@ def dense_rows_topk(h: torch.Tensor, k: int, min_similarity: float, *, row0: int
                                           score.data_ptr(), count.data_ptr(), _stream_ptr())
     native.check(rc, "tvbf_dense_rows_topk_f64")
     return idx, score, count
+
+
+def query_topk(z_q: torch.Tensor, z_all: torch.Tensor, k: int, min_similarity: float, *,
+               self_index=None, n: int | None = None, workspace: torch.Tensor | None = None) -> TopK:
+    """Neighbours of a few query vectors (1..64 rows of ``z_q``) among the first ``n`` rows of
+    ``z_all``: one memory-bound pass over ``z_all``.  ``self_index[i]`` is the column left out
+    for query i (-1 or None: nothing)."""
+    _require_cuda(z_all, "z_all")
+    _require_cuda(z_q, "z_q")
+    if z_all.dim() != 2 or not z_all.is_contiguous() or z_q.dim() != 2 or z_q.stride(1) != 1:
+        raise ValueError("z_all must be contiguous 2-D and z_q 2-D with contiguous rows")
+    if z_q.shape[1] != z_all.shape[1]:
+        raise ValueError("z_q and z_all must have the same row length")
+    nq = z_q.shape[0]
+    n = z_all.shape[0] if n is None else int(n)
+    if not 1 <= n <= z_all.shape[0]:
+        raise ValueError("n outside z_all")
+    if not 1 <= nq <= native.TVBF_MAX_QUERIES:
+        raise ValueError(f"1..{native.TVBF_MAX_QUERIES} queries per call")
+    if not 1 <= k <= native.TVBF_MAX_K:
+        raise ValueError(f"k must be in 1..{native.TVBF_MAX_K}")
+    selfs = None
+    if self_index is not None:
+        vals = [int(v) for v in self_index]
+        if len(vals) != nq:
+            raise ValueError("self_index needs one entry per query")
+        selfs = (ctypes.c_int64 * nq)(*vals)
+    dev = z_all.device
+    out = TopK(torch.empty((nq, k), dtype=torch.int32, device=dev),
+               torch.empty((nq, k), dtype=torch.float32, device=dev),
+               torch.empty((nq,), dtype=torch.int32, device=dev))
+    lib = native.load()
+    with torch.cuda.device(dev):
+        need = int(lib.tvbf_query_workspace_bytes(nq, n, k))
+        if workspace is None:
+            workspace = torch.empty((need + 15) // 16 * 2, dtype=torch.int64, device=dev)
+        ws_bytes = workspace.numel() * workspace.element_size()
+        rc = lib.tvbf_query_topk_f32(z_q.data_ptr(), nq, z_q.stride(0) if nq > 1 else z_q.shape[1], selfs,
+                                     z_all.data_ptr(), n, z_all.shape[1], z_all.shape[1], k, float(min_similarity),
+                                     out.idx.data_ptr(), out.score.data_ptr(), out.count.data_ptr(),
+                                     workspace.data_ptr(), ws_bytes, _stream_ptr())
+    native.check(rc, "tvbf_query_topk_f32")
+    return out
 
 
 class TopkSession:

@@ -31,6 +31,8 @@ SYMBOLS = (
     "tvbf_topk_begin",
     "tvbf_topk_accumulate_f32",
     "tvbf_topk_finish",
+    "tvbf_query_workspace_bytes",
+    "tvbf_query_topk_f32",
     "tvbf_gram_f32",
     "tvbf_component_scores_f32",
     "tvbf_weighted_sum3_f64",
@@ -42,6 +44,7 @@ SYMBOLS = (
 TVBF_MAX_BLOCKS = 8
 TVBF_MAX_K = 100
 TVBF_MAX_SOURCES = 8
+TVBF_MAX_QUERIES = 64
 SRC_DENSE_F32, SRC_DENSE_F64, SRC_DENSE_I64, SRC_DENSE_U8, SRC_CSR_F32, SRC_CSR_F64 = range(6)
 
 
@@ -134,6 +137,11 @@ def load() -> ctypes.CDLL:
                                              vp, sz, c.c_int, c.c_int, c.POINTER(c.c_int), vp]
     lib.tvbf_topk_finish.restype = c.c_int
     lib.tvbf_topk_finish.argtypes = [i64, c.c_int, c.c_int, vp, vp, vp, vp, sz, vp]
+    lib.tvbf_query_workspace_bytes.restype = sz
+    lib.tvbf_query_workspace_bytes.argtypes = [i64, i64, c.c_int]
+    lib.tvbf_query_topk_f32.restype = c.c_int
+    lib.tvbf_query_topk_f32.argtypes = [vp, i64, i64, c.POINTER(i64), vp, i64, i64, i64, c.c_int, f32,
+                                        vp, vp, vp, vp, sz, vp]
     lib.tvbf_gram_f32.restype = c.c_int
     lib.tvbf_gram_f32.argtypes = [vp, i64, vp, i64, i64, i64, vp, i64, vp]
     lib.tvbf_weighted_sum3_f64.restype = c.c_int

@@ -2,7 +2,9 @@
 ``ContentBasedRecommendationService`` (services/content_based_service.py):
 ``_load_similarity_matrices`` (:113-140), ``_load_show_mappings`` (:142-159),
 ``get_recommendations_from_matrix`` (:161-236) and
-``compute_and_store_all_similarities`` (:262-338).
+``compute_and_store_all_similarities`` (:262-338), plus
+``get_recommendations_from_features``: the same lookup computed from the feature
+files, for catalogues whose n x n matrices cannot be stored.
 
 The three dense matrices are loaded from disk as in the reference; the hybrid
 matrix is formed on the GPU with the same float64 arithmetic (bit for bit),
@@ -48,6 +50,8 @@ class ContentBasedRecommendationService:
         self._text_similarity = None
         self._metadata_similarity = None
         self._hybrid_similarity = None
+        self._feature_z = None             # torch fp32 (n, ld): per-block unit rows, kept in HBM
+        self._feature_layout = None
         self._show_id_to_index: dict | None = None
         self._index_to_show_id: dict | None = None
         logger.info("Initialized ContentBasedRecommendationService")
@@ -128,6 +132,63 @@ class ContentBasedRecommendationService:
         show_idx = self._show_id_to_index[show_id]
         idx, score, count, comps = self._rank_rows(show_idx, 1, n_eff, min_similarity)
         return self._records(idx[0], score[0], int(count[0]), [c[0] for c in comps], "show_id")
+
+    def _load_feature_matrix(self):
+        """The five feature files of scripts/compute_features.py:115-129 -> block-normalised Z
+        on the GPU (unit scale per block, so any weighting can be applied to a query vector)."""
+        if self._feature_z is not None:
+            return
+        import torch
+
+        from .. import engine, features as feat
+        from ..scripts.compute_similarities import load_features
+
+        dev = self._device()
+        sources, layout = feat.block_sources(load_features(self._get_data_dir()), 1.0, 1.0, 1.0, "computer")
+        dev_sources = []
+        for src in sources:
+            if src[0] == "dense":
+                dev_sources.append(engine.DenseSource(torch.from_numpy(src[1]).to(dev), src[2]))
+            else:
+                _, indptr, indices, data, width, z_col = src
+                dev_sources.append(engine.CsrSource(torch.from_numpy(indptr).to(dev), torch.from_numpy(indices).to(dev),
+                                                    torch.from_numpy(data).to(dev), width, z_col))
+        n = int(sources[0][1].shape[0]) - (1 if sources[0][0] == "csr" else 0)
+        self._feature_z = engine.assemble_normalize(dev_sources, n, layout.offsets, [1.0] * layout.nb)
+        self._feature_layout = layout
+        logger.info(f"✓ Feature matrix on device: {tuple(self._feature_z.shape)}")
+
+    def get_recommendations_from_features(self, show_id: int, n: int = 10, min_similarity: float = 0.0,
+                                          genre_weight: float | None = None, text_weight: float | None = None,
+                                          metadata_weight: float | None = None) -> list:
+        """Same records as :meth:`get_recommendations_from_matrix`, computed from the feature
+        files with one pass over the catalogue instead of stored n x n matrices; the weights
+        default to the service's and may differ per call (normalised by their sum as in the
+        reference, services/content_based_service.py:133-138)."""
+        from .. import engine
+
+        self._load_feature_matrix()
+        self._load_show_mappings()
+        if show_id not in self._show_id_to_index:
+            logger.warning(f"Show ID {show_id} not found in similarity matrix")
+            return []
+        gw = self.genre_weight if genre_weight is None else genre_weight
+        tw = self.text_weight if text_weight is None else text_weight
+        mw = self.metadata_weight if metadata_weight is None else metadata_weight
+        total = gw + tw + mw
+        weights = [gw / total, tw / total, mw / total]
+        if min(weights) < 0:
+            raise ValueError("similarity weights must be >= 0")
+        z, layout = self._feature_z, self._feature_layout
+        row = self._show_id_to_index[show_id]
+        q = z[row:row + 1].clone()
+        for b in range(layout.nb):
+            q[:, layout.offsets[b]:layout.offsets[b + 1]] *= weights[b]
+        top = engine.query_topk(q, z, max(n, 1), min_similarity, self_index=[row])
+        comp = engine.component_scores(z, layout.offsets, [1.0] * layout.nb, top.idx, q_row0=row)
+        comp = comp.cpu().numpy()[0]
+        return self._records(top.idx.cpu().numpy()[0], top.score.cpu().numpy()[0], int(top.count.cpu().numpy()[0]),
+                             [comp[:, 0], comp[:, 1], comp[:, 2]], "show_id")
 
     def _records(self, idx, score, count, comps, id_key):
         return [
