@@ -264,6 +264,22 @@ int tvbf_query_topk_f32(const float* Zq, int64_t nq, int64_t ldq, const int64_t*
                         float min_similarity, int32_t* out_idx, float* out_score,
                         int32_t* out_count, void* workspace, size_t workspace_bytes, void* stream);
 
+/*
+ * Statistics of the strict upper triangle of Z Z^T -- mean, population standard
+ * deviation, min, max, median -- without storing the matrix: three sweeps of the
+ * tile engine (sums / extrema / radix histograms of the median's key).  Replaces
+ * get_similarity_statistics (ml/similarity_computer.py:171-190, called four times by
+ * scripts/compute_similarities.py:119-131) for catalogues whose n x n matrix does not
+ * fit; values are the fp32 scores of tvbf_gram_f32, sums are float64.
+ *
+ *   Z          device, n x d fp32 (n >= 2), row stride ld; d % 32 == 0, ld % 4 == 0
+ *   out5       device, 5 doubles: mean, std, min, max, median
+ *   workspace  device, >= tvbf_gram_stats_workspace_bytes(n) bytes, 16-byte aligned
+ */
+size_t tvbf_gram_stats_workspace_bytes(int64_t n);
+int tvbf_gram_stats_f32(const float* Z, int64_t n, int64_t d, int64_t ld, double* out5,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,73 @@
+"""Statistics of the strict upper triangle of Z Z^T without the matrix (three tile sweeps)."""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from oracle import similarity_oracle as so
+from synth import dense_gaussian, hybrid_like_blocks
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("mean", "std", "min", "max", "median")
+
+
+def _ref_stats(h):
+    iu = np.triu_indices_from(h, k=1)
+    v = h[iu]
+    return np.array([v.mean(), v.std(), v.min(), v.max(), np.median(v)])
+
+
+@pytest.mark.parametrize("n,d", [(2, 32), (3, 8), (129, 40), (700, 96), (1500, 256)])
+def test_gram_stats_match_numpy(pkg, device, n, d):
+    import torch
+
+    from tvbingefriend_recommendation_service_amd import engine
+
+    x = dense_gaussian(n, d, seed=n * 7 + d)
+    z = engine.normalize_blocks(torch.from_numpy(x).to(device), [0, d], [1.0])
+    got = engine.gram_stats(z).cpu().numpy()
+    # exact reference on the kernel's own fp32 scores: min / max / median are order statistics
+    s32 = engine.gram(z).cpu().numpy().astype(np.float64)
+    ref32 = _ref_stats(s32)
+    assert got[2] == ref32[2] and got[3] == ref32[3] and got[4] == ref32[4]
+    assert abs(got[0] - ref32[0]) <= 1e-12 and abs(got[1] - ref32[1]) <= 1e-9
+    # and within the fp32 tolerance of the float64 oracle
+    zo = so.l2_normalize_rows(x.astype(np.float64))
+    ref = _ref_stats(zo @ zo.T)
+    assert np.abs(got - ref).max() <= 1e-5
+
+
+def test_feature_statistics_match_reference_semantics(pkg, device):
+    from tvbingefriend_recommendation_service_amd.ml.similarity_computer import SimilarityComputer
+
+    f = hybrid_like_blocks(900, 5, d_genre=20, d_text=150, as_features=True)
+    got = SimilarityComputer(0.4, 0.5, 0.1).get_feature_statistics(f)
+    oracle = so.SimilarityComputerOracle(0.4, 0.5, 0.1)
+    sims = oracle.compute_all_similarities(f)
+    assert set(got) == set(sims)
+    for name, m in sims.items():
+        ref = oracle.get_similarity_statistics(m)
+        assert set(got[name]) == set(KEYS)
+        for key in KEYS:
+            assert isinstance(got[name][key], float)
+            assert abs(got[name][key] - ref[key]) <= 1e-5, (name, key, got[name][key], ref[key])
+
+
+def test_gram_stats_rejects_bad_arguments(pkg, device):
+    import torch
+
+    from tvbingefriend_recommendation_service_amd import engine, native
+
+    z = torch.zeros((4, 32), dtype=torch.float32, device=device)
+    with pytest.raises(ValueError):
+        engine.gram_stats(z[:1])
+    lib = native.load()
+    assert lib.tvbf_gram_stats_workspace_bytes(1) == 0
+    out = torch.zeros(5, dtype=torch.float64, device=device)
+    rc = lib.tvbf_gram_stats_f32(z.data_ptr(), 4, 32, 32, out.data_ptr(), out.data_ptr(), 8, None)
+    assert rc == -2 and b"workspace" in lib.tvbf_last_error()
+    # an all-zero matrix: every statistic is 0
+    got = engine.gram_stats(z).cpu().numpy()
+    assert np.all(got == 0)

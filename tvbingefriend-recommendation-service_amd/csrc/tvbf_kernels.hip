@@ -160,9 +160,21 @@ struct TopkArgs {
     int row_blocks, splits, col_tiles;
     float min_similarity;
     int exclude_self;
-    float* gram;  // GRAM mode: dense nq x n output, row stride ldo
+    float* gram;  // dense-matrix mode: nq x n output, row stride ldo
     int64_t ldo;
+    // statistics mode: strict upper triangle of Z Z^T, never stored
+    double* st_part;            // [workgroups][4]: sum, sum of squares, min, max
+    unsigned* st_hist;          // [2][ST_BINS] radix histograms of the two median ranks
+    const unsigned* st_prefix;  // [2] key prefixes selected by the earlier levels
+    int st_level, st_chunk;     // radix level 0..2; column tiles per workgroup
 };
+
+// radix select of the median over ordered 32-bit keys: 11 + 11 + 10 bits
+constexpr int ST_BINS = 2048;
+__host__ __device__ constexpr int st_shift(int level) { return level == 0 ? 21 : level == 1 ? 10 : 0; }
+__host__ __device__ constexpr int st_bits(int level) { return level == 2 ? 10 : 11; }
+
+enum { MODE_TOPK = 0, MODE_GRAM = 1, MODE_STATS = 2 };
 
 __device__ static inline f32x4 load_chunk(const char* p) {
 #ifdef TVBF_DIAG_NO_LOADS  // timing-only build: no global traffic
@@ -234,11 +246,15 @@ __device__ static inline void compact_row(u64* buf, unsigned* cnt, u64* mkey, in
     __builtin_amdgcn_wave_barrier();
 }
 
+// MODE_STATS: the dense-matrix orientation with an epilogue that folds the strict upper
+// triangle into sums, extrema and a radix histogram instead of storing it.
 // GRAM = false: fused top-K (scores stay on chip).  GRAM = true: the same tile
 // engine with the operands swapped (lane = column, registers = query rows) and
 // an epilogue that stores the tile, for callers that need the dense matrix.
-template <bool GRAM>
+template <int MODE>
 __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a) {
+    constexpr bool GRAM = MODE != MODE_TOPK;  // operands swapped: lane = column, registers = query rows
+    static_assert(MODE != MODE_STATS || BM == BN, "the triangle walk assumes square tiles");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* tileQ = reinterpret_cast<float*>(smem);
     float* tileC = tileQ + BM * LDT;
@@ -254,8 +270,15 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
 
     const int rb = blockIdx.x % a.row_blocks;
     const int split = blockIdx.x / a.row_blocks;
-    const int tile_begin = (int)(((int64_t)a.col_tiles * split) / a.splits);
-    const int tile_end = (int)(((int64_t)a.col_tiles * (split + 1)) / a.splits);
+    int tile_begin, tile_end;
+    if (MODE == MODE_STATS) {  // chunk `split` of the tiles on and right of the diagonal (BM == BN)
+        tile_begin = rb + split * a.st_chunk;
+        tile_end = tile_begin + a.st_chunk < a.col_tiles ? tile_begin + a.st_chunk : a.col_tiles;
+        if (tile_begin > tile_end) tile_begin = tile_end;
+    } else {
+        tile_begin = (int)(((int64_t)a.col_tiles * split) / a.splits);
+        tile_end = (int)(((int64_t)a.col_tiles * (split + 1)) / a.splits);
+    }
     const int64_t q0 = (int64_t)rb * BM;  // first query row (local to zq)
 
     // ---- per-row candidate buffers (rows of wave w are touched by wave w only) ----
@@ -319,6 +342,19 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    // statistics mode: per-lane running values and the workgroup's LDS histograms
+    double st_sum = 0.0, st_sq = 0.0;
+    float st_min = INFINITY, st_max = -INFINITY;
+    unsigned* st_lds = reinterpret_cast<unsigned*>(tileC + BN * LDT);  // [2][ST_BINS]
+    unsigned st_pre0 = 0u, st_pre1 = 0u;
+    if (MODE == MODE_STATS) {
+        for (int i = tid; i < 2 * ST_BINS; i += TOPK_THREADS) st_lds[i] = 0u;
+        if (a.st_level > 0) {
+            st_pre0 = a.st_prefix[0];
+            st_pre1 = a.st_prefix[1];
+        }
+    }
 
     int ct = tile_begin, kb = 0;
     if (total > 0) load_regs(ct, kb);
@@ -385,7 +421,39 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
             for (int j = 0; j < NJ; ++j) cf[j] = cn[j];
         }
 
-        if (GRAM && kb == nkb - 1) {
+        if (MODE == MODE_STATS && kb == nkb - 1) {
+            // lane = column (lane & 31) of sub-tile j, registers = query rows of this wave;
+            // only pairs row < column < n count
+            const int64_t col0 = (int64_t)ct * BN;
+            const int64_t n_cols = a.rng[0].n;
+            const int sh = st_shift(a.st_level), prev = a.st_level == 0 ? 32 : st_shift(a.st_level - 1);
+            const unsigned mask = (1u << st_bits(a.st_level)) - 1u;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int64_t c = col0 + 32 * j + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t qr = q0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const float v = acc[j][r];
+                    acc[j][r] = 0.f;
+                    if (qr < c && c < n_cols) {
+                        const unsigned key = f32_to_ordered(v);
+                        if (a.st_level == 0) {
+                            st_sum += (double)v;
+                            st_sq += (double)v * (double)v;
+                            st_min = fminf(st_min, v);
+                            st_max = fmaxf(st_max, v);
+                            atomicAdd(&st_lds[key >> sh], 1u);
+                        } else {
+                            const unsigned pre = key >> prev;
+                            if (pre == st_pre0) atomicAdd(&st_lds[(key >> sh) & mask], 1u);
+                            if (pre == st_pre1 && st_pre1 != st_pre0) atomicAdd(&st_lds[ST_BINS + ((key >> sh) & mask)], 1u);
+                        }
+                    }
+                }
+            }
+        }
+        if (MODE == MODE_GRAM && kb == nkb - 1) {
             // lane = column (lane & 31) of sub-tile j, registers = query rows of this wave
             const int64_t col0 = (int64_t)ct * BN;  // dense-matrix mode uses one range only
             const int64_t n_cols = a.rng[0].n;
@@ -502,6 +570,32 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
         kb = nkbi;
     }
 
+    if (MODE == MODE_STATS) {
+        // every workgroup leaves its sums in its own slot (folded later in a fixed order) and
+        // adds its histogram to the global one (integer adds: order does not matter)
+        __syncthreads();
+        for (int i = tid; i < 2 * ST_BINS; i += TOPK_THREADS) {
+            const unsigned v = st_lds[i];
+            if (v) atomicAdd(&a.st_hist[i], v);
+        }
+        if (a.st_level == 0) {
+            double* red = reinterpret_cast<double*>(tileQ);  // [4][TOPK_THREADS]
+            red[tid] = st_sum;
+            red[TOPK_THREADS + tid] = st_sq;
+            red[2 * TOPK_THREADS + tid] = (double)st_min;
+            red[3 * TOPK_THREADS + tid] = (double)st_max;
+            __syncthreads();
+            if (tid < 4) {
+                double acc0 = red[tid * TOPK_THREADS];
+                for (int i = 1; i < TOPK_THREADS; ++i) {
+                    const double x = red[tid * TOPK_THREADS + i];
+                    acc0 = tid < 2 ? acc0 + x : tid == 2 ? fmin(acc0, x) : fmax(acc0, x);
+                }
+                a.st_part[(int64_t)blockIdx.x * 4 + tid] = acc0;
+            }
+        }
+        return;
+    }
     if (GRAM) return;
     // ---- final compaction and publication of this split's lists (per wave) ----
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -724,6 +818,87 @@ __global__ __launch_bounds__(256) void query_select_kernel(const float* __restri
 }
 
 // --------------------------------------------------------------------------
+// statistics of the strict upper triangle of Z Z^T without the matrix:
+// level-0 sweep (sums, extrema, first radix histogram), two more sweeps that
+// refine the median's key, small kernels in between that pick the bins.
+// --------------------------------------------------------------------------
+struct GramStatsWs {
+    unsigned hist[2 * ST_BINS];
+    unsigned prefix[2];
+    unsigned long long rank[2];  // 0-based ascending ranks of the two middle elements
+    double part[1];              // [workgroups][4], variable length
+};
+
+__global__ __launch_bounds__(256) void gram_stats_init_kernel(GramStatsWs* ws, unsigned long long count) {
+    for (int i = threadIdx.x; i < 2 * ST_BINS; i += 256) ws->hist[i] = 0u;
+    if (threadIdx.x < 2) {
+        ws->prefix[threadIdx.x] = 0u;
+        ws->rank[threadIdx.x] = threadIdx.x == 0 ? (count - 1) / 2 : count / 2;
+    }
+}
+
+__global__ __launch_bounds__(256) void gram_stats_pick_kernel(GramStatsWs* ws, int level) {
+    __shared__ unsigned new_prefix[2];
+    __shared__ unsigned long long new_rank[2];
+    const int t = threadIdx.x;
+    if (t < 2) {
+        const bool one_hist = level == 0 || ws->prefix[0] == ws->prefix[1];
+        const unsigned* h = ws->hist + ((t == 1 && !one_hist) ? ST_BINS : 0);
+        const unsigned long long rank = ws->rank[t];
+        unsigned long long cum = 0;
+        const int bins = 1 << st_bits(level);
+        int b = 0;
+        for (; b < bins - 1; ++b) {
+            if (cum + h[b] > rank) break;
+            cum += h[b];
+        }
+        new_prefix[t] = (level == 0 ? 0u : ws->prefix[t] << st_bits(level)) | (unsigned)b;
+        new_rank[t] = rank - cum;
+    }
+    __syncthreads();
+    if (t < 2) {
+        ws->prefix[t] = new_prefix[t];
+        ws->rank[t] = new_rank[t];
+    }
+    for (int i = t; i < 2 * ST_BINS; i += 256) ws->hist[i] = 0u;
+}
+
+__global__ __launch_bounds__(256) void gram_stats_final_kernel(const GramStatsWs* ws, int64_t wgs,
+                                                               unsigned long long count, double* __restrict__ out5) {
+    __shared__ double red[4][256];
+    const int t = threadIdx.x;
+    double sum = 0.0, sq = 0.0, mn = INFINITY, mx = -INFINITY;
+    for (int64_t i = t; i < wgs; i += 256) {  // fixed assignment and order: same bits on every run
+        sum += ws->part[i * 4 + 0];
+        sq += ws->part[i * 4 + 1];
+        mn = fmin(mn, ws->part[i * 4 + 2]);
+        mx = fmax(mx, ws->part[i * 4 + 3]);
+    }
+    red[0][t] = sum, red[1][t] = sq, red[2][t] = mn, red[3][t] = mx;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < s) {
+            red[0][t] += red[0][t + s];
+            red[1][t] += red[1][t + s];
+            red[2][t] = fmin(red[2][t], red[2][t + s]);
+            red[3][t] = fmax(red[3][t], red[3][t + s]);
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        const double c = (double)count;
+        const double mean = red[0][0] / c;
+        double var = red[1][0] / c - mean * mean;
+        if (var < 0.0) var = 0.0;
+        out5[0] = mean;
+        out5[1] = sqrt(var);
+        out5[2] = red[2][0];
+        out5[3] = red[3][0];
+        out5[4] = 0.5 * ((double)ordered_to_f32(ws->prefix[0]) + (double)ordered_to_f32(ws->prefix[1]));
+    }
+}
+
+// --------------------------------------------------------------------------
 // host side
 // --------------------------------------------------------------------------
 struct Plan {
@@ -932,7 +1107,7 @@ int tvbf_topk_accumulate_f32(const float* Zq, int64_t nq, int64_t q_row0, int64_
     const int64_t grid = (int64_t)p.row_blocks * p.splits;
     if (grid > INT32_MAX) return fail(TVBF_E_BAD_ARG, "too many workgroups");
     if (p.lds_bytes > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(cosine_tile_kernel<false>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(cosine_tile_kernel<MODE_TOPK>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
     TopkArgs a;
     memset(&a, 0, sizeof(a));
@@ -953,7 +1128,7 @@ int tvbf_topk_accumulate_f32(const float* Zq, int64_t nq, int64_t q_row0, int64_
     a.col_tiles = tiles;
     a.min_similarity = min_similarity;
     a.exclude_self = exclude_self;
-    hipLaunchKernelGGL(cosine_tile_kernel<false>, dim3((unsigned)grid), dim3(TOPK_THREADS), p.lds_bytes,
+    hipLaunchKernelGGL(cosine_tile_kernel<MODE_TOPK>, dim3((unsigned)grid), dim3(TOPK_THREADS), p.lds_bytes,
                        (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     *slots_used = p.splits;
@@ -1100,8 +1275,70 @@ int tvbf_gram_f32(const float* Zq, int64_t nq, const float* Zall, int64_t n, int
     a.bound = nullptr;
     const int64_t grid = (int64_t)a.row_blocks * a.splits;
     if (grid > INT32_MAX) return fail(TVBF_E_BAD_ARG, "too many workgroups");
-    hipLaunchKernelGGL(cosine_tile_kernel<true>, dim3((unsigned)grid), dim3(TOPK_THREADS),
+    hipLaunchKernelGGL(cosine_tile_kernel<MODE_GRAM>, dim3((unsigned)grid), dim3(TOPK_THREADS),
                        (size_t)(BM + BN) * LDT * sizeof(float), (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return TVBF_OK;
+}
+
+static int gram_stats_chunk(int tiles) {
+    int c = (tiles + 63) / 64;
+    return c < 16 ? 16 : c;
+}
+
+size_t tvbf_gram_stats_workspace_bytes(int64_t n) {
+    if (n < 2 || n > INT32_MAX - BN) return 0;
+    const int tiles = tiles_of(n);
+    const int chunk = gram_stats_chunk(tiles);
+    const size_t wgs = (size_t)tiles * (size_t)((tiles + chunk - 1) / chunk);
+    return (sizeof(GramStatsWs) + wgs * 4 * sizeof(double) + 255) / 256 * 256;
+}
+
+int tvbf_gram_stats_f32(const float* Z, int64_t n, int64_t d, int64_t ld, double* out5, void* workspace,
+                        size_t workspace_bytes, void* stream) {
+    if (!Z || !out5 || !workspace) return fail(TVBF_E_BAD_ARG, "null pointer argument");
+    if (n < 2) return fail(TVBF_E_BAD_ARG, "statistics of the upper triangle need n >= 2");
+    if (n > INT32_MAX - BN || d < 1 || d > INT32_MAX - BK) return fail(TVBF_E_BAD_ARG, "n or d too large");
+    if ((d % BK) || (ld & 3) || ld < d)
+        return fail(TVBF_E_BAD_SHAPE, "d must be a multiple of 32 and ld a multiple of 4, ld >= d");
+    if (((uintptr_t)Z & 15) || ((uintptr_t)workspace & 15)) return fail(TVBF_E_BAD_SHAPE, "Z and workspace must be 16-byte aligned");
+    if (ld > (INT32_MAX / 4) / (BM + BN)) return fail(TVBF_E_BAD_SHAPE, "ld too large");
+    const size_t need = tvbf_gram_stats_workspace_bytes(n);
+    if (workspace_bytes < need) return fail(TVBF_E_BAD_SHAPE, "workspace must be >= %zu bytes", need);
+    GramStatsWs* ws = reinterpret_cast<GramStatsWs*>(workspace);
+    const int tiles = tiles_of(n);
+    const int chunk = gram_stats_chunk(tiles);
+    const int chunks = (tiles + chunk - 1) / chunk;
+    const int64_t wgs = (int64_t)tiles * chunks;
+    if (wgs > INT32_MAX) return fail(TVBF_E_BAD_ARG, "too many workgroups");
+    const unsigned long long count = (unsigned long long)n * (unsigned long long)(n - 1) / 2;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)(BM + BN) * LDT * sizeof(float) + 2 * ST_BINS * sizeof(unsigned);
+    if (lds > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(cosine_tile_kernel<MODE_STATS>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(gram_stats_init_kernel, dim3(1), dim3(256), 0, st, ws, count);
+    TopkArgs a;
+    memset(&a, 0, sizeof(a));
+    a.zq = Z;
+    a.rng[0] = ColRange{Z, n, 0, tiles};
+    a.rng[1] = ColRange{Z, 0, 0, 0};
+    a.nq = n;
+    a.ld = ld;
+    a.d = (int)d;
+    a.row_blocks = tiles;
+    a.col_tiles = tiles;
+    a.splits = chunks;
+    a.st_part = ws->part;
+    a.st_hist = ws->hist;
+    a.st_prefix = ws->prefix;
+    a.st_chunk = chunk;
+    for (int level = 0; level < 3; ++level) {
+        a.st_level = level;
+        hipLaunchKernelGGL(cosine_tile_kernel<MODE_STATS>, dim3((unsigned)wgs), dim3(TOPK_THREADS), lds, st, a);
+        hipLaunchKernelGGL(gram_stats_pick_kernel, dim3(1), dim3(256), 0, st, ws, level);
+    }
+    hipLaunchKernelGGL(gram_stats_final_kernel, dim3(1), dim3(256), 0, st, ws, wgs, count, out5);
     HIP_TRY(hipGetLastError());
     return TVBF_OK;
 }

@@ -286,6 +286,26 @@ def upper_tri_stats(m: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def gram_stats(z: torch.Tensor, n: int | None = None) -> torch.Tensor:
+    """{mean, std, min, max, median} of the strict upper triangle of ``z[:n] @ z[:n].T`` (5 doubles
+    on the GPU); the matrix is never stored.  ``z`` is (rows >= n, ld) fp32 with ld % 32 == 0."""
+    _require_cuda(z, "z")
+    if z.dim() != 2 or not z.is_contiguous():
+        raise ValueError("z must be a contiguous 2-D tensor")
+    n = z.shape[0] if n is None else int(n)
+    if not 2 <= n <= z.shape[0]:
+        raise ValueError("statistics of the upper triangle need 2 <= n <= rows of z")
+    lib = native.load()
+    out = torch.empty(5, dtype=torch.float64, device=z.device)
+    ws_bytes = int(lib.tvbf_gram_stats_workspace_bytes(n))
+    ws = torch.empty(ws_bytes // 8, dtype=torch.int64, device=z.device)
+    with torch.cuda.device(z.device):
+        rc = lib.tvbf_gram_stats_f32(z.data_ptr(), n, z.shape[1], z.shape[1], out.data_ptr(), ws.data_ptr(),
+                                     ws_bytes, _stream_ptr())
+    native.check(rc, "tvbf_gram_stats_f32")
+    return out
+
+
 def dense_rows_topk(h: torch.Tensor, k: int, min_similarity: float, *, row0: int = 0, rows: int | None = None,
                     exclude_self: bool = True):
     """Top-k of rows ``row0 .. row0+rows`` of a dense float64 score matrix (n, n) on the GPU.

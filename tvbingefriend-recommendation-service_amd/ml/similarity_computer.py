@@ -169,6 +169,39 @@ class SimilarityComputer:
         return {"mean": float(out[0]), "std": float(out[1]), "min": float(out[2]),
                 "max": float(out[3]), "median": float(out[4])}
 
+    def get_feature_statistics(self, features: dict) -> dict:
+        """The four statistics blocks that scripts/compute_similarities.py:119-131 logs (genre,
+        text, metadata, hybrid), each what :meth:`get_similarity_statistics` returns for that
+        matrix, computed from the features without forming any n x n matrix."""
+        import torch
+
+        from .. import engine
+
+        dev = _torch_device(self.device)
+        sources, layout = feat.block_sources(features, self.genre_weight, self.text_weight,
+                                             self.metadata_weight, "computer")
+        n = int(sources[0][1].shape[0]) - (1 if sources[0][0] == "csr" else 0)
+        if n < 2:
+            raise ValueError("zero-size array to reduction operation minimum which has no identity")
+        dev_sources = []
+        for src in sources:
+            if src[0] == "dense":
+                dev_sources.append(engine.DenseSource(torch.from_numpy(src[1]).to(dev), src[2]))
+            else:
+                _, indptr, indices, data, width, z_col = src
+                dev_sources.append(engine.CsrSource(torch.from_numpy(indptr).to(dev), torch.from_numpy(indices).to(dev),
+                                                    torch.from_numpy(data).to(dev), width, z_col))
+        out = {}
+        hybrid_scales = layout.scales()
+        for name, scales in (("genre_similarity", [1.0, 0.0, 0.0]), ("text_similarity", [0.0, 1.0, 0.0]),
+                             ("metadata_similarity", [0.0, 0.0, 1.0]), ("hybrid_similarity", hybrid_scales)):
+            # a block with scale 0 contributes nothing to the product: one layout serves all four
+            z = engine.assemble_normalize(dev_sources, n, layout.offsets, scales)
+            v = engine.gram_stats(z).cpu().numpy()
+            out[name] = {"mean": float(v[0]), "std": float(v[1]), "min": float(v[2]),
+                         "max": float(v[3]), "median": float(v[4])}
+        return out
+
     # ---- scalable entry point: no n x n matrix ----
 
     def topk(self, features: dict, k: int = 20, min_similarity: float = 0.1,

@@ -34,6 +34,8 @@ SYMBOLS = (
     "tvbf_query_workspace_bytes",
     "tvbf_query_topk_f32",
     "tvbf_gram_f32",
+    "tvbf_gram_stats_workspace_bytes",
+    "tvbf_gram_stats_f32",
     "tvbf_component_scores_f32",
     "tvbf_weighted_sum3_f64",
     "tvbf_stats_workspace_bytes",
@@ -144,6 +146,10 @@ def load() -> ctypes.CDLL:
                                         vp, vp, vp, vp, sz, vp]
     lib.tvbf_gram_f32.restype = c.c_int
     lib.tvbf_gram_f32.argtypes = [vp, i64, vp, i64, i64, i64, vp, i64, vp]
+    lib.tvbf_gram_stats_workspace_bytes.restype = sz
+    lib.tvbf_gram_stats_workspace_bytes.argtypes = [i64]
+    lib.tvbf_gram_stats_f32.restype = c.c_int
+    lib.tvbf_gram_stats_f32.argtypes = [vp, i64, i64, i64, vp, vp, sz, vp]
     lib.tvbf_weighted_sum3_f64.restype = c.c_int
     lib.tvbf_weighted_sum3_f64.argtypes = [vp, vp, vp, c.c_double, c.c_double, c.c_double, vp, i64, vp]
     lib.tvbf_stats_workspace_bytes.restype = sz
