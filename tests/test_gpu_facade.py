@@ -303,3 +303,20 @@ def test_service_feature_path_matches_matrix_semantics(pkg, device, tmp_path):
                     assert abs(a["metadata_score"] - o["metadata_similarity"][row, j]) <= SCORE_TOL
                     assert a["show_id"] != sid
     assert svc.get_recommendations_from_features(-5) == []
+
+
+def test_populate_columnar_sink_equals_dict_sink(pkg, device, tmp_path):
+    """An array-native sink gets the same pairs, in the same order, with the same values as the
+    record dicts handed to a SimilarityRepository-like sink."""
+    from tvbingefriend_recommendation_service_amd.scripts import populate_database as pd_amd
+
+    g = load_golden("plumbing_100")
+    _write_feature_dir(tmp_path, g)
+    dict_sink, col_sink = pd_amd.MemorySimilaritySink(), pd_amd.ColumnarSimilaritySink()
+    s1 = pd_amd.compute_and_store_similarities(tmp_path, 0.4, 0.5, 0.1, repo=dict_sink)
+    s2 = pd_amd.compute_and_store_similarities(tmp_path, 0.4, 0.5, 0.1, repo=col_sink)
+    assert s1["total_records"] == s2["total_records"] and s1["unique_shows"] == s2["unique_shows"]
+    flat = [(sid, r["similar_show_id"], r["similarity_score"], r["genre_score"], r["text_score"], r["metadata_score"])
+            for sid, items in dict_sink.records.items() for r in items]
+    rows = [row for batch in col_sink.rows(1000) for row in batch]
+    assert rows == flat

@@ -253,3 +253,47 @@ def test_block_sources_match_packed_layout(pkg):
         assert kinds == [np.int64, "csr", np.float64, np.bool_, np.float64]  # nothing converted on the host
     with pytest.raises(KeyError):
         feat.block_sources({"genre_features": f["genre_features"]}, 0.4, 0.5, 0.1)
+
+
+def test_columnar_table_equals_record_dicts(pkg, tmp_path):
+    """neighbour_table / iter_table_rows / write_table_csv carry exactly the pairs and values of
+    the record dicts (scripts/populate_database.py:210-221 of the reference), in the same order."""
+    import csv
+
+    from tvbingefriend_recommendation_service_amd.ml.similarity_computer import TopKResult
+    from tvbingefriend_recommendation_service_amd.scripts import populate_database as pd_
+
+    rng = np.random.default_rng(4)
+    n, k = 40, 6
+    count = rng.integers(0, k + 1, size=n).astype(np.int32)
+    count[3] = 0
+    idx = np.full((n, k), -1, dtype=np.int32)
+    score = np.zeros((n, k), dtype=np.float32)
+    comp = np.zeros((n, k, 3), dtype=np.float64)
+    for r in range(n):
+        c = count[r]
+        idx[r, :c] = rng.choice(n, size=c, replace=False)
+        score[r, :c] = np.sort(rng.random(c).astype(np.float32))[::-1]
+        comp[r, :c] = rng.random((c, 3))
+    ids = [1000 + 7 * i for i in range(n)]
+    res = TopKResult(idx, score, count, comp)
+    recs = pd_.neighbour_records(res, ids, 0, n)
+    table = pd_.neighbour_table(res, ids)
+    flat = [(sid, r["similar_show_id"], r["similarity_score"], r["genre_score"], r["text_score"], r["metadata_score"])
+            for sid, items in recs.items() for r in items]
+    rows = [row for batch in pd_.iter_table_rows(table, batch_size=7) for row in batch]
+    assert rows == flat and all(type(v) in (int, float) for v in rows[0])
+    assert all(len(b) <= 7 for b in pd_.iter_table_rows(table, batch_size=7))
+    path = tmp_path / "pairs.csv"
+    assert pd_.write_table_csv(table, path) == len(flat)
+    with open(path, newline="") as f:
+        got = list(csv.reader(f))
+    assert tuple(got[0]) == pd_.TABLE_COLUMNS and len(got) == len(flat) + 1
+    for line, ref in zip(got[1:], flat):
+        assert int(line[0]) == ref[0] and int(line[1]) == ref[1]
+        assert np.float32(float(line[2])) == np.float32(ref[2])
+        assert all(abs(float(a) - b) <= 1e-9 for a, b in zip(line[3:], ref[3:]))
+    sink = pd_.ColumnarSimilaritySink()
+    assert sink.store_similarity_table(table) == len(flat)
+    st = sink.get_similarity_stats()
+    assert st["total_records"] == len(flat) and st["unique_shows"] == len(recs)

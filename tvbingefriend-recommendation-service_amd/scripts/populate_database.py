@@ -17,7 +17,6 @@ from pathlib import Path
 
 import numpy as np
 
-from .. import features as feat
 from ..ml.similarity_computer import SimilarityComputer, TopKResult
 from .compute_similarities import load_features
 
@@ -48,6 +47,56 @@ def neighbour_records(result: TopKResult, show_ids, start: int, stop: int) -> di
     return out
 
 
+# column order of the reference's show_similarities table (models/show_similarity.py:19-29)
+TABLE_COLUMNS = ("show_id", "similar_show_id", "similarity_score", "genre_score", "text_score",
+                 "metadata_score")
+
+
+def neighbour_table(result: TopKResult, show_ids) -> dict:
+    """All kept pairs as six flat columns, in (show, rank) order -- the rows the reference
+    builds one ORM object at a time (repos/similarity_repository.py:97-108), here as arrays
+    for ``executemany`` / bulk loaders.  No Python object per pair is created."""
+    ids = np.asarray(show_ids)
+    k = result.idx.shape[1]
+    keep = np.arange(k)[None, :] < np.asarray(result.count)[:, None]
+    rows, slots = np.nonzero(keep)  # row-major: shows ascending, ranks ascending
+    comp = np.asarray(result.comp)
+    return {
+        "show_id": ids[rows],
+        "similar_show_id": ids[np.asarray(result.idx)[rows, slots]],
+        "similarity_score": np.asarray(result.score, dtype=np.float64)[rows, slots],
+        "genre_score": comp[rows, slots, 0].astype(np.float64),
+        "text_score": comp[rows, slots, 1].astype(np.float64),
+        "metadata_score": comp[rows, slots, 2].astype(np.float64),
+    }
+
+
+def iter_table_rows(table: dict, batch_size: int = 1000):
+    """Batches of plain tuples (column order ``TABLE_COLUMNS``) for a DB-API ``executemany``;
+    the batch size mirrors the reference's commit interval (repos/similarity_repository.py:75)."""
+    n = len(table["show_id"])
+    cols = [table[c] for c in TABLE_COLUMNS]
+    for start in range(0, n, batch_size):
+        stop = min(n, start + batch_size)
+        yield list(zip(*[c[start:stop].tolist() for c in cols]))
+
+
+def write_table_csv(table: dict, path, header: bool = True) -> int:
+    """The table as a CSV file for a bulk loader (``LOAD DATA INFILE`` / ``COPY``); returns the
+    number of rows.  Scores are written with 9 significant digits (exact for fp32)."""
+    n = len(table["show_id"])
+    with open(path, "w", encoding="utf-8", newline="") as f:
+        if header:
+            f.write(",".join(TABLE_COLUMNS) + "\n")
+        block = 65536
+        for start in range(0, n, block):
+            stop = min(n, start + block)
+            cols = [table[c][start:stop] for c in TABLE_COLUMNS]
+            lines = ["%d,%d,%.9g,%.9g,%.9g,%.9g" % row for row in zip(*[c.tolist() for c in cols])]
+            f.write("\n".join(lines) + "\n")
+    return n
+
+
 def compute_top_neighbours(features: dict, genre_weight: float = 0.4, text_weight: float = 0.5,
                            metadata_weight: float = 0.1, top_n_per_show: int = 20,
                            min_similarity: float = 0.1, device=None) -> TopKResult:
@@ -62,6 +111,9 @@ def compute_and_store_similarities(input_dir: Path, genre_weight: float = 0.4, t
                                    metadata_weight: float = 0.1, top_n_per_show: int = 20,
                                    min_similarity: float = 0.1, repo=None, clear_existing=None) -> dict:
     """Compute the top-N neighbours of every show and store them.
+
+    A sink that also has ``store_similarity_table(table: dict) -> int`` receives the six flat
+    columns of :func:`neighbour_table` once instead of record dicts in batches.
 
     ``repo`` is the sink: any object with ``bulk_store_all_similarities(dict,
     clear_existing=False) -> int`` and ``get_similarity_stats() -> dict`` (the
@@ -104,12 +156,15 @@ def compute_and_store_similarities(input_dir: Path, genre_weight: float = 0.4, t
         result = compute_top_neighbours(features, genre_weight, text_weight, metadata_weight,
                                         top_n_per_show, min_similarity)
         total_records_stored = 0
-        for start in range(0, n, FLUSH_EVERY):
-            stop = min(n, start + FLUSH_EVERY)
-            batch = neighbour_records(result, show_ids, start, stop)
-            if batch:
-                total_records_stored += repo.bulk_store_all_similarities(batch, clear_existing=False)
-            logger.info(f"  Processed {stop}/{n} shows... (stored {total_records_stored} similarity records)")
+        if hasattr(repo, "store_similarity_table"):  # array-native sink: no per-pair Python objects
+            total_records_stored = int(repo.store_similarity_table(neighbour_table(result, show_ids)))
+        else:
+            for start in range(0, n, FLUSH_EVERY):
+                stop = min(n, start + FLUSH_EVERY)
+                batch = neighbour_records(result, show_ids, start, stop)
+                if batch:
+                    total_records_stored += repo.bulk_store_all_similarities(batch, clear_existing=False)
+                logger.info(f"  Processed {stop}/{n} shows... (stored {total_records_stored} similarity records)")
         logger.info(f"✓ Stored {total_records_stored} total similarity records")
 
         stats = repo.get_similarity_stats()
@@ -120,6 +175,30 @@ def compute_and_store_similarities(input_dir: Path, genre_weight: float = 0.4, t
     finally:
         if db is not None:
             db.close()
+
+
+class ColumnarSimilaritySink:
+    """Array-native sink: keeps the six columns of :func:`neighbour_table`; ``rows()`` and
+    ``to_csv()`` feed an ``executemany`` or a bulk loader."""
+
+    def __init__(self):
+        self.table = {c: np.empty(0) for c in TABLE_COLUMNS}
+
+    def store_similarity_table(self, table: dict) -> int:
+        self.table = table
+        return len(table["show_id"])
+
+    def rows(self, batch_size: int = 1000):
+        return iter_table_rows(self.table, batch_size)
+
+    def to_csv(self, path, header: bool = True) -> int:
+        return write_table_csv(self.table, path, header)
+
+    def get_similarity_stats(self) -> dict:
+        total = len(self.table["show_id"])
+        shows = len(np.unique(self.table["show_id"])) if total else 0
+        return {"total_records": total, "unique_shows": shows,
+                "avg_similarities_per_show": (total / shows) if shows else 0, "last_computed": None}
 
 
 class MemorySimilaritySink:
