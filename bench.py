@@ -32,13 +32,15 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=100_000, help="shows")
-    ap.add_argument("--d", type=int, default=1024, help="feature columns (genre 32 | text d-64 | metadata 32)")
-    ap.add_argument("--k", type=int, default=20)
+    ap.add_argument("--n", "--shows", dest="n", type=int, default=100_000, help="shows")
+    ap.add_argument("--d", "--dims", dest="d", type=int, default=1024, help="feature columns (genre 32 | text d-64 | metadata 32)")
+    ap.add_argument("--k", "--neighbours", dest="k", type=int, default=20)
     ap.add_argument("--data", choices=["hybrid", "dense"], default="hybrid")
     ap.add_argument("--min-similarity", type=float, default=None)
     ap.add_argument("--seed", type=int, default=30001)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo is a rehearsal mode: the shards are exchanged through host memory")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline sample")
     return ap.parse_args()
 
@@ -128,10 +130,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    dev = torch.device(f"cuda:{local_rank}")
+    dev = torch.device(f"cuda:{local_rank % torch.cuda.device_count()}")
     torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     min_sim = args.min_similarity
     if min_sim is None:
@@ -155,9 +160,28 @@ def main():
     kernel_ms = []
     own, after, before = sharding.column_pieces(shard)
 
+    class HostGather:
+        """gloo rehearsal: CPU tensors only, copied synchronously to and from the device."""
+
+        def __init__(self):
+            host = z_shard.cpu()
+            parts = [torch.empty_like(host) for _ in range(world)]
+            dist.all_gather(parts, host)
+            self.full = torch.cat(parts, dim=0)
+
+        def wait(self):
+            z_all.copy_(self.full)
+
+    def start_gather():
+        if world == 1:
+            return None
+        if args.backend == "nccl":
+            return dist.all_gather_into_tensor(z_all, z_shard, async_op=True)
+        return HostGather()
+
     def step(timed):
         engine.normalize_blocks(x, offsets, scales, out=z_shard)
-        work = dist.all_gather_into_tensor(z_all, z_shard, async_op=True) if world > 1 else None
+        work = start_gather()
         session = engine.TopkSession(z_shard, nq, shard.row0, args.k, min_sim, slots=slots, workspace=workspace)
         if timed:
             ev[0].record()
@@ -180,6 +204,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(v):
+        t = torch.tensor([v], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     for _ in range(args.warmup):
         step(False)
     barrier()
@@ -189,12 +218,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        km = torch.tensor([sum(kernel_ms) / max(len(kernel_ms), 1)], dtype=torch.float64, device=dev)
-        dist.all_reduce(km, op=dist.ReduceOp.MAX)
-        kernel_avg_ms = float(km.item())
+        elapsed = max_over_ranks(elapsed)
+        kernel_avg_ms = max_over_ranks(sum(kernel_ms) / max(len(kernel_ms), 1))
     else:
         kernel_avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
 
@@ -225,11 +250,11 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": workload, "rows_per_gpu": per_rank_rows,
-                   "parallelism": f"row-shard x{world} + all-gather" if world > 1 else "single GPU"},
+                   "parallelism": f"row-shard x{world} + all-gather ({args.backend})" if world > 1 else "single GPU"},
         "topk_build_time_s": elapsed / args.steps,
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                     "kernel": "cosine_tile_kernel<false> (HIP events also span the 4 us bound fill and the "
+                     "kernel": "cosine_tile_kernel<0> (HIP events also span the 4 us bound fill and the "
                                "0.3 ms list merge of the same call)", "kernel_ms": kernel_avg_ms},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
