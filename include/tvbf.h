@@ -19,7 +19,7 @@
  *   - all device work is enqueued on `stream` (a hipStream_t passed as
  *     void*; NULL = the default stream); the caller synchronises;
  *   - the library allocates no device memory: scratch comes in through the
- *     `workspace` argument, sized by tvbf_topk_workspace_bytes();
+ *     `workspace` argument, sized by the matching *_workspace_bytes() call;
  *   - no global mutable state: concurrent calls from different host threads
  *     on different streams/devices are safe.
  */

@@ -157,6 +157,7 @@ struct TopkArgs {
     unsigned* bound;  // [nq] best known lower bound of every row's K-th score (ordered bits)
     int64_t nq, q_row0, ld;
     int d, k, cap;
+    int list_global;  // K too large for LDS lists next to a second workgroup: lists live in `partial`
     int row_blocks, splits, col_tiles;
     float min_similarity;
     int exclude_self;
@@ -246,6 +247,73 @@ __device__ static inline void compact_row(u64* buf, unsigned* cnt, u64* mkey, in
     __builtin_amdgcn_wave_barrier();
 }
 
+// Large K: the row's list does not fit LDS beside a second resident workgroup.  LDS then
+// holds only a staging buffer of `cap` new candidates per row; the list itself (K keys,
+// descending, empty slots = sentinel) lives in the split's own output slot in global memory,
+// which stays L2-resident.  merge_row_global ranks staged + listed keys together (three keys
+// per lane, <= 192), writes the K best back and refreshes the threshold.  A list is read and
+// written by one wavefront only, so workgroup-scope fences order its traffic: the vector L1 is
+// shared by the waves of a CU and written through, and no cache maintenance is needed (wider
+// scopes would write back and invalidate the XCD's L2 on every merge).
+__device__ static inline void merge_row_global(u64* stg, unsigned* cnt, u64* mkey, u64* glist, u64* scr, int k,
+                                               int cap, int lane, unsigned* gbound, u64 empty) {
+    int valid = (int)*cnt;
+    if (valid > cap) valid = cap;
+    valid = __builtin_amdgcn_readfirstlane(valid);
+    if (valid == 0) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (int i = lane; i < k; i += 64) scr[i] = __hip_atomic_load(glist + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (int i = lane; i < valid; i += 64) scr[k + i] = stg[i];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int m = k + valid;
+    u64 my[3];
+    int rk[3];
+    bool real[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int i = lane + 64 * u;
+        my[u] = i < m ? scr[i] : 0ull;
+        real[u] = i < m && (uint32_t)my[u] != 0u;  // sentinels are not ranked
+        rk[u] = 0;
+    }
+    int i = 0;
+#pragma nounroll
+    for (; i + 8 <= m; i += 8) {
+        u64 o[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) o[u] = scr[i + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            rk[0] += o[u] > my[0] ? 1 : 0;
+            rk[1] += o[u] > my[1] ? 1 : 0;
+            rk[2] += o[u] > my[2] ? 1 : 0;
+        }
+    }
+#pragma nounroll
+    for (; i < m; ++i) {
+        const u64 o = scr[i];
+        rk[0] += o > my[0] ? 1 : 0;
+        rk[1] += o > my[1] ? 1 : 0;
+        rk[2] += o > my[2] ? 1 : 0;
+    }
+    int n_real = 0;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        n_real += __builtin_popcountll(__ballot(real[u]));
+        if (real[u] && rk[u] < k) __hip_atomic_store(glist + rk[u], my[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (real[u] && rk[u] == k - 1) {
+            *mkey = my[u];
+            if (gbound) atomicMax(gbound, (unsigned)(my[u] >> 32));
+        }
+    }
+    for (int j = n_real + lane; j < k; j += 64) __hip_atomic_store(glist + j, empty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0) *cnt = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // MODE_STATS: the dense-matrix orientation with an epilogue that folds the strict upper
 // triangle into sums, extrema and a radix histogram instead of storing it.
 // GRAM = false: fused top-K (scores stay on chip).  GRAM = true: the same tile
@@ -261,6 +329,7 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
     u64* buf_all = reinterpret_cast<u64*>(tileC + BN * LDT);  // [BM][cap]
     u64* mkey_all = buf_all + (size_t)BM * a.cap;               // [BM]
     unsigned* cnt_all = reinterpret_cast<unsigned*>(mkey_all + BM);  // [BM]
+    u64* merge_scr = reinterpret_cast<u64*>(cnt_all + BM);           // [4][k + cap], global-list mode only
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -282,16 +351,26 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
     const int64_t q0 = (int64_t)rb * BM;  // first query row (local to zq)
 
     // ---- per-row candidate buffers (rows of wave w are touched by wave w only) ----
+    // global-list mode: padded rows (>= nq) have no list to merge into, so nothing may pass
+    const bool dead_row = !GRAM && a.list_global && q0 + lrow >= a.nq;
     if (!GRAM && tid < BM) {
-        mkey_all[tid] = sentinel_key(a.min_similarity);
+        mkey_all[tid] = (a.list_global && q0 + tid >= a.nq) ? ~0ull : sentinel_key(a.min_similarity);
         cnt_all[tid] = 0u;
+    }
+    if (!GRAM && a.list_global) {  // this split's lists of the wave's rows start empty
+        int64_t rows = a.nq - (q0 + wave * 32);
+        rows = rows < 0 ? 0 : rows > 32 ? 32 : rows;
+        u64* g = a.partial + ((int64_t)split * a.nq + q0 + wave * 32) * a.k;
+        for (int64_t i = lane; i < rows * a.k; i += 64)
+            __hip_atomic_store(g + i, sentinel_key(a.min_similarity), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     }
     u64* my_buf = buf_all + (size_t)lrow * a.cap;
     u64* my_mkey = mkey_all + lrow;
     unsigned* my_cnt = cnt_all + lrow;
-    u64 mkey = sentinel_key(a.min_similarity);  // register copy of the row's threshold key
-    float thr = a.min_similarity;               // max(its score part, the row's global bound)
-    float gbf = a.min_similarity;               // last value read from the global bound
+    u64 mkey = dead_row ? ~0ull : sentinel_key(a.min_similarity);  // register copy of the row's threshold key
+    float thr = dead_row ? INFINITY : a.min_similarity;  // max(its score part, the row's global bound)
+    float gbf = a.min_similarity;                        // last value read from the global bound
     // padded rows (>= nq) repeat the last real row but without its self exclusion:
     // they neither read nor publish bounds
     unsigned* my_gb = (!GRAM && q0 + lrow < a.nq) ? a.bound + q0 + lrow : nullptr;
@@ -548,8 +627,14 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
                                     const int l = (int)__builtin_ctzll(full) & 31;
                                     const int row = wave * 32 + l;
                                     const int64_t qr = q0 + row;
-                                    compact_row(buf_all + (size_t)row * a.cap, cnt_all + row, mkey_all + row, a.k,
-                                                a.cap, lane, qr < a.nq ? a.bound + qr : nullptr);
+                                    if (a.list_global)
+                                        merge_row_global(buf_all + (size_t)row * a.cap, cnt_all + row, mkey_all + row,
+                                                         a.partial + ((int64_t)split * a.nq + qr) * a.k,
+                                                         merge_scr + (size_t)wave * (a.k + a.cap), a.k, a.cap, lane,
+                                                         a.bound + qr, sentinel_key(a.min_similarity));
+                                    else
+                                        compact_row(buf_all + (size_t)row * a.cap, cnt_all + row, mkey_all + row, a.k,
+                                                    a.cap, lane, qr < a.nq ? a.bound + qr : nullptr);
                                     full &= ~((1ull << l) | (1ull << (l + 32)));
                                 }
                                 mkey = *my_mkey;
@@ -606,6 +691,12 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
         const int row = wave * 32 + l;
         const int64_t qr = q0 + row;
         if (qr >= a.nq) break;
+        if (a.list_global) {  // the list already sits in its output slot: fold in what is still staged
+            merge_row_global(buf_all + (size_t)row * a.cap, cnt_all + row, mkey_all + row,
+                             a.partial + ((int64_t)split * a.nq + qr) * a.k,
+                             merge_scr + (size_t)wave * (a.k + a.cap), a.k, a.cap, lane, a.bound + qr, empty);
+            continue;
+        }
         compact_row(buf_all + (size_t)row * a.cap, cnt_all + row, mkey_all + row, a.k, a.cap, lane, a.bound + qr);
         const int have = (int)cnt_all[row];
         u64* dst = a.partial + ((int64_t)split * a.nq + qr) * a.k;
@@ -916,13 +1007,24 @@ static int device_cus() {
     return cus;
 }
 
-// Buffer entries per row: K plus slack so that compactions are amortised over
-// several accepted candidates.  K <= 30 keeps two workgroups per CU (<= 80 KB
-// each); K <= 52 uses 64 entries (one key per lane in a compaction).
+// K <= 30: the whole list of a row lives in LDS, K plus 12 slack entries so that compactions
+// are amortised over several accepted candidates; two workgroups fit a CU (<= 80 KB each).
+// Larger K: the list lives in global memory and LDS holds 32 staged candidates per row plus
+// one merge scratch per wave, which again fits two workgroups per CU for every K <= 100.
+// TVBF_LIST=lds forces the LDS lists for any K (one workgroup per CU above 30): a tuning aid.
+static bool topk_list_global(int k) {
+    if (const char* e = getenv("TVBF_LIST")) {
+        if (!strcmp(e, "lds")) return false;
+        if (!strcmp(e, "global")) return true;
+    }
+    return k > 30;
+}
+
 static int topk_cap(int k) {
 #if TVBF_BN == 256
     if (k <= 20) return 24;  // keeps two workgroups per CU with the wider column tile
 #endif
+    if (topk_list_global(k)) return 32;
     if (k <= 30) return k + 12;
     if (k <= 52) return 64;
     return k + 12;
@@ -931,8 +1033,9 @@ static int topk_cap(int k) {
 static size_t topk_lds_bytes(int k) {
     size_t pad = 0;
     if (const char* e = getenv("TVBF_LDS_PAD")) pad = (size_t)atoi(e);  // tuning aid: forces one workgroup per CU
+    const size_t merge_scratch = topk_list_global(k) ? (size_t)4 * (k + topk_cap(k)) * 8 : 0;
     return pad + (size_t)(BM + BN) * LDT * sizeof(float) + (size_t)BM * topk_cap(k) * 8 + (size_t)BM * 8 +
-           (size_t)BM * 4;
+           (size_t)BM * 4 + merge_scratch;
 }
 
 // Column splits trade tail balance (more, shorter workgroups) against repeated
@@ -1123,6 +1226,7 @@ int tvbf_topk_accumulate_f32(const float* Zq, int64_t nq, int64_t q_row0, int64_
     a.d = (int)d;
     a.k = k;
     a.cap = topk_cap(k);
+    a.list_global = topk_list_global(k) ? 1 : 0;
     a.row_blocks = p.row_blocks;
     a.splits = p.splits;
     a.col_tiles = tiles;
