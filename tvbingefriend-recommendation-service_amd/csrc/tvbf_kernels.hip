@@ -157,7 +157,6 @@ struct TopkArgs {
     unsigned* bound;  // [nq] best known lower bound of every row's K-th score (ordered bits)
     int64_t nq, q_row0, ld;
     int d, k, cap;
-    int list_global;  // K too large for LDS lists next to a second workgroup: lists live in `partial`
     int row_blocks, splits, col_tiles;
     float min_similarity;
     int exclude_self;
@@ -175,7 +174,8 @@ constexpr int ST_BINS = 2048;
 __host__ __device__ constexpr int st_shift(int level) { return level == 0 ? 21 : level == 1 ? 10 : 0; }
 __host__ __device__ constexpr int st_bits(int level) { return level == 2 ? 10 : 11; }
 
-enum { MODE_TOPK = 0, MODE_GRAM = 1, MODE_STATS = 2 };
+// MODE_TOPK_G is MODE_TOPK with the lists in global memory (large K)
+enum { MODE_TOPK = 0, MODE_GRAM = 1, MODE_STATS = 2, MODE_TOPK_G = 3 };
 
 __device__ static inline f32x4 load_chunk(const char* p) {
 #ifdef TVBF_DIAG_NO_LOADS  // timing-only build: no global traffic
@@ -321,7 +321,8 @@ __device__ static inline void merge_row_global(u64* stg, unsigned* cnt, u64* mke
 // an epilogue that stores the tile, for callers that need the dense matrix.
 template <int MODE>
 __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a) {
-    constexpr bool GRAM = MODE != MODE_TOPK;  // operands swapped: lane = column, registers = query rows
+    constexpr bool GRAM = MODE == MODE_GRAM || MODE == MODE_STATS;  // operands swapped: lane = column, registers = query rows
+    constexpr bool LIST_GLOBAL = MODE == MODE_TOPK_G;
     static_assert(MODE != MODE_STATS || BM == BN, "the triangle walk assumes square tiles");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* tileQ = reinterpret_cast<float*>(smem);
@@ -352,12 +353,12 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
 
     // ---- per-row candidate buffers (rows of wave w are touched by wave w only) ----
     // global-list mode: padded rows (>= nq) have no list to merge into, so nothing may pass
-    const bool dead_row = !GRAM && a.list_global && q0 + lrow >= a.nq;
+    const bool dead_row = !GRAM && LIST_GLOBAL && q0 + lrow >= a.nq;
     if (!GRAM && tid < BM) {
-        mkey_all[tid] = (a.list_global && q0 + tid >= a.nq) ? ~0ull : sentinel_key(a.min_similarity);
+        mkey_all[tid] = (LIST_GLOBAL && q0 + tid >= a.nq) ? ~0ull : sentinel_key(a.min_similarity);
         cnt_all[tid] = 0u;
     }
-    if (!GRAM && a.list_global) {  // this split's lists of the wave's rows start empty
+    if (!GRAM && LIST_GLOBAL) {  // this split's lists of the wave's rows start empty
         int64_t rows = a.nq - (q0 + wave * 32);
         rows = rows < 0 ? 0 : rows > 32 ? 32 : rows;
         u64* g = a.partial + ((int64_t)split * a.nq + q0 + wave * 32) * a.k;
@@ -627,7 +628,7 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
                                     const int l = (int)__builtin_ctzll(full) & 31;
                                     const int row = wave * 32 + l;
                                     const int64_t qr = q0 + row;
-                                    if (a.list_global)
+                                    if (LIST_GLOBAL)
                                         merge_row_global(buf_all + (size_t)row * a.cap, cnt_all + row, mkey_all + row,
                                                          a.partial + ((int64_t)split * a.nq + qr) * a.k,
                                                          merge_scr + (size_t)wave * (a.k + a.cap), a.k, a.cap, lane,
@@ -691,7 +692,7 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
         const int row = wave * 32 + l;
         const int64_t qr = q0 + row;
         if (qr >= a.nq) break;
-        if (a.list_global) {  // the list already sits in its output slot: fold in what is still staged
+        if (LIST_GLOBAL) {  // the list already sits in its output slot: fold in what is still staged
             merge_row_global(buf_all + (size_t)row * a.cap, cnt_all + row, mkey_all + row,
                              a.partial + ((int64_t)split * a.nq + qr) * a.k,
                              merge_scr + (size_t)wave * (a.k + a.cap), a.k, a.cap, lane, a.bound + qr, empty);
@@ -1209,9 +1210,11 @@ int tvbf_topk_accumulate_f32(const float* Zq, int64_t nq, int64_t q_row0, int64_
     if (workspace_bytes < need) return fail(TVBF_E_BAD_SHAPE, "workspace must be >= %zu bytes", need);
     const int64_t grid = (int64_t)p.row_blocks * p.splits;
     if (grid > INT32_MAX) return fail(TVBF_E_BAD_ARG, "too many workgroups");
+    const bool list_global = topk_list_global(k);
+    const void* kernel = list_global ? reinterpret_cast<const void*>(cosine_tile_kernel<MODE_TOPK_G>)
+                                     : reinterpret_cast<const void*>(cosine_tile_kernel<MODE_TOPK>);
     if (p.lds_bytes > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(cosine_tile_kernel<MODE_TOPK>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
+        HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
     TopkArgs a;
     memset(&a, 0, sizeof(a));
     a.zq = Zq;
@@ -1226,14 +1229,17 @@ int tvbf_topk_accumulate_f32(const float* Zq, int64_t nq, int64_t q_row0, int64_
     a.d = (int)d;
     a.k = k;
     a.cap = topk_cap(k);
-    a.list_global = topk_list_global(k) ? 1 : 0;
     a.row_blocks = p.row_blocks;
     a.splits = p.splits;
     a.col_tiles = tiles;
     a.min_similarity = min_similarity;
     a.exclude_self = exclude_self;
-    hipLaunchKernelGGL(cosine_tile_kernel<MODE_TOPK>, dim3((unsigned)grid), dim3(TOPK_THREADS), p.lds_bytes,
-                       (hipStream_t)stream, a);
+    if (list_global)
+        hipLaunchKernelGGL(cosine_tile_kernel<MODE_TOPK_G>, dim3((unsigned)grid), dim3(TOPK_THREADS), p.lds_bytes,
+                           (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(cosine_tile_kernel<MODE_TOPK>, dim3((unsigned)grid), dim3(TOPK_THREADS), p.lds_bytes,
+                           (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     *slots_used = p.splits;
     return TVBF_OK;
