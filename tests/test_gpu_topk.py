@@ -238,3 +238,34 @@ def test_large_shape_properties(pkg, device):
     for o, r in enumerate(rows):
         check_topk_against_scores(h[o : o + 1], int(r), k, ms, idx[r : r + 1], score[r : r + 1], count[r : r + 1],
                                   what=f"N=100k row {r}")
+
+
+def test_wide_features_large_k_two_ranges(pkg, device):
+    """The shape class of the largest configuration (D = 2048, K = 50, a row shard in the middle of
+    the catalogue, columns given as two ranges): lists in global memory, 64-bit row offsets.
+    Sampled rows against the float64 oracle, all rows against a single-range sweep."""
+    import torch
+
+    from tvbingefriend_recommendation_service_amd import engine
+
+    n, d, k, row0, nq = 150_000, 2048, 50, 70_000, 3000
+    gen = torch.Generator(device=device)
+    gen.manual_seed(9)
+    x = torch.randn((n, d), generator=gen, device=device)
+    z = engine.normalize_blocks(x, [0, d], [1.0])
+    zq = z[row0:row0 + nq].contiguous()
+    ses = engine.TopkSession(zq, nq, row0, k, -1.0)
+    ses.accumulate((zq, nq, row0))
+    ses.accumulate((z[row0 + nq:], n - row0 - nq, row0 + nq), (z, row0, 0))
+    top = ses.finish()
+    one = engine.cosine_topk(z, k, -1.0, q_row0=row0, nq=nq)
+    torch.cuda.synchronize()
+    idx, score, count = _to_np(top.idx), _to_np(top.score), _to_np(top.count)
+    assert np.array_equal(idx, _to_np(one.idx)) and np.array_equal(score, _to_np(one.score))
+    assert np.all(count == k)
+    rows = np.random.default_rng(1).choice(nq, size=12, replace=False)
+    zo = so.l2_normalize_rows(x.cpu().numpy().astype(np.float64))
+    h = zo[row0 + rows] @ zo.T
+    for o, r in enumerate(rows):
+        check_topk_against_scores(h[o:o + 1], int(row0 + r), k, -1.0, idx[r:r + 1], score[r:r + 1],
+                                  count[r:r + 1], what=f"wide row {r}")
