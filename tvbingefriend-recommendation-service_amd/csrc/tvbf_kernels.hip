@@ -397,22 +397,35 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
     const int total = (tile_end - tile_begin) * nkb;
 
     f32x4 rq[4], rc[NJ];
+    // Per-thread byte offsets of the column-tile rows, refreshed only when the tile changes (the
+    // last tile of a range clamps rows past its end); a k-block then needs no vector arithmetic
+    // for addresses, which matters because ordinary VALU work competes with the MFMA issue.
+    unsigned coff[NJ];
+    auto set_tile = [&](int ct) {
+        const ColRange& cr = a.rng[ct >= a.rng[0].tiles ? 1 : 0];
+        const int64_t trow = (int64_t)(ct >= a.rng[0].tiles ? ct - a.rng[0].tiles : ct) * BN;
+        const int64_t last = cr.n - 1 - trow;  // last valid row of this tile
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) {
+            int64_t r = sr + 32 * i;
+            if (r > last) r = last;
+            coff[i] = (unsigned)((r * a.ld + sc * 4) * 4);
+        }
+        // The query offsets never change, but the compiler must not know: as loop invariants they
+        // would be widened to 64 bits outside the loop and cost a 64-bit vector add per load.
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(qoff[i]));
+    };
     auto load_regs = [&](int ct, int kb) {
         const char* qb = qbase + (size_t)kb * (BK * 4);
         const ColRange& cr = a.rng[ct >= a.rng[0].tiles ? 1 : 0];
         const int64_t trow = (int64_t)(ct >= a.rng[0].tiles ? ct - a.rng[0].tiles : ct) * BN;  // tile's first row
         const char* cb = reinterpret_cast<const char*>(cr.z + trow * a.ld) + (size_t)kb * (BK * 4);
-        const int64_t last = cr.n - 1 - trow;  // last valid row of this tile
 #pragma unroll
         for (int i = 0; i < 4; ++i) rq[i] = load_chunk(qb + qoff[i]);
 #pragma unroll
-        for (int i = 0; i < NJ; ++i) {
-            int64_t r = sr + 32 * i;
-            if (r > last) r = last;
-            rc[i] = load_chunk(cb + (unsigned)((r * a.ld + sc * 4) * 4));
-        }
+        for (int i = 0; i < NJ; ++i) rc[i] = load_chunk(cb + coff[i]);
     };
-
     const float* q_lds = tileQ + lrow * LDT + half * 4;
     const float* c_lds = tileC + (lane & 31) * LDT + half * 4;
     float* scratch = tileQ + wave * 32 * LDT;  // this wave's own query rows, free in the epilogue
@@ -436,8 +449,27 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
         }
     }
 
+#if defined(TVBF_STAGGER)
+    // Experiment: give co-resident workgroups different phases of the k-block cycle.
+    {
+        int units = 0;  // 512-cycle units
+#if TVBF_STAGGER == 1  // pseudo-random per workgroup, 0..15 units
+        units = (int)((blockIdx.x * 2654435761u) >> 28);
+#elif TVBF_STAGGER == 2  // first round only: the workgroup in the odd wave slot waits half a period
+        const unsigned hw = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);  // HW_ID[3:0] = wave slot
+        units = (blockIdx.x < 512u && (hw & 1u)) ? 9 : 0;
+#elif TVBF_STAGGER == 3  // every workgroup in an odd wave slot
+        const unsigned hw = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);
+        units = (hw & 1u) ? 9 : 0;
+#endif
+        for (int u = 0; u < units; ++u) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
     int ct = tile_begin, kb = 0;
-    if (total > 0) load_regs(ct, kb);
+    if (total > 0) {
+        set_tile(ct);
+        load_regs(ct, kb);
+    }
     __syncthreads();  // lists initialised
 
 #ifdef TVBF_DIAG_NO_BARRIER  // timing-only build (results are wrong)
@@ -445,20 +477,52 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
 #else
 #define TILE_SYNC() __syncthreads()
 #endif
+#ifdef TVBF_DIAG_TIMELINE  // timing-only build: every wave sums the cycle counter deltas between six marks
+    unsigned long long* tl_buf = reinterpret_cast<unsigned long long*>(a.gram);
+    unsigned long long tl_sum[6] = {0, 0, 0, 0, 0, 0}, tl_prev = 0, tl_n = 0;
+    unsigned tl_cnt[4] = {0, 0, 0, 0};  // sub-tile slow paths, pop rounds, appended keys (lane 0..63 total), compactions
+    unsigned long long tl_in[3] = {0, 0, 0}, tl_t0 = 0, tl_t1 = 0;  // cycles in slow paths, of these before the pop loop, in compactions
+#define TL_COUNT_EVENT(i, v) tl_cnt[i] += (v)
+#define TL_BEGIN(var) do { __builtin_amdgcn_sched_barrier(0); var = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define TL_END(var, i) do { __builtin_amdgcn_sched_barrier(0); tl_in[i] += __builtin_readcyclecounter() - var; __builtin_amdgcn_sched_barrier(0); } while (0)
+    const bool tl_on = tl_buf != nullptr;
+#define TL_MARK(slot)                                                   \
+    do {                                                                \
+        if (tl_on) {                                                    \
+            __builtin_amdgcn_sched_barrier(0);                          \
+            const unsigned long long t_ = __builtin_readcyclecounter(); \
+            if (tl_prev) tl_sum[slot] += t_ - tl_prev;                  \
+            tl_prev = t_;                                               \
+            __builtin_amdgcn_sched_barrier(0);                          \
+        }                                                               \
+    } while (0)
+#else
+#define TL_MARK(slot) do { } while (0)
+#define TL_COUNT_EVENT(i, v) do { } while (0)
+#define TL_BEGIN(var) do { } while (0)
+#define TL_END(var, i) do { } while (0)
+#endif
     for (int it = 0; it < total; ++it) {
+        TL_MARK(0);
         TILE_SYNC();  // everyone is done with the previous LDS tile (and epilogue scratch)
+        TL_MARK(1);
 #pragma unroll
         for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(qdst + 32 * i * LDT) = rq[i];
 #pragma unroll
         for (int i = 0; i < NJ; ++i) *reinterpret_cast<f32x4*>(cdst + 32 * i * LDT) = rc[i];
+        TL_MARK(2);
         TILE_SYNC();
+        TL_MARK(3);
         // prefetch the next k-block into registers while the MFMAs run
         int nct = ct, nkbi = kb + 1;
         if (nkbi == nkb) {
             nkbi = 0;
             ++nct;
         }
-        if (it + 1 < total) load_regs(nct, nkbi);
+        if (it + 1 < total) {
+            if (nkbi == 0) set_tile(nct);
+            load_regs(nct, nkbi);
+        }
         unsigned gb_bits = 0u;
         if (!GRAM && kb == 0 && my_gb)  // consumed a whole tile later: latency is free
             gb_bits = __hip_atomic_load(my_gb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -501,6 +565,7 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
             for (int j = 0; j < NJ; ++j) cf[j] = cn[j];
         }
 
+        TL_MARK(4);
         if (MODE == MODE_STATS && kb == nkb - 1) {
             // lane = column (lane & 31) of sub-tile j, registers = query rows of this wave;
             // only pairs row < column < n count
@@ -596,14 +661,18 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
 #else
                 if (__any(m >= thr)) {
 #endif
+                    TL_COUNT_EVENT(0, 1);
+                    TL_BEGIN(tl_t0);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) scratch[r * 64 + lane] = acc[j][r];
                     // which of this lane's 16 scores pass: a bit mask built from registers
                     unsigned bits = 0u;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) bits |= acc[j][r] >= thr ? (1u << r) : 0u;
+                    TL_END(tl_t0, 1);
                     // one round per remaining candidate of the busiest lane
                     while (__any(bits != 0u)) {
+                        TL_COUNT_EVENT(1, 1);
                         const bool has = bits != 0u;
                         const int r = has ? __builtin_ctz(bits) : 0;
                         bits &= bits - 1u;
@@ -611,6 +680,7 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
                         const int c = (int)col0 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * half;
                         const u64 key = make_key(v, c);
                         bool cand = has && v >= thr && key > mkey;
+                        TL_COUNT_EVENT(2, __builtin_popcountll(__ballot(cand)));
                         while (__any(cand)) {
                             if (cand) {
                                 const unsigned pos = atomicAdd(my_cnt, 1u);
@@ -624,7 +694,9 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
                                 // some buffers are full: compact those rows, then retry what is left
                                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                                 __builtin_amdgcn_wave_barrier();
+                                TL_BEGIN(tl_t1);
                                 while (full) {
+                                    TL_COUNT_EVENT(3, 1);
                                     const int l = (int)__builtin_ctzll(full) & 31;
                                     const int row = wave * 32 + l;
                                     const int64_t qr = q0 + row;
@@ -638,12 +710,14 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
                                                     a.cap, lane, qr < a.nq ? a.bound + qr : nullptr);
                                     full &= ~((1ull << l) | (1ull << (l + 32)));
                                 }
+                                TL_END(tl_t1, 2);
                                 mkey = *my_mkey;
                                 thr = fmaxf(ordered_to_f32((uint32_t)(mkey >> 32)), gbf);
                                 cand = cand && v >= thr && key > mkey;
                             }
                         }
                     }
+                    TL_END(tl_t0, 0);
                 }
             }
 #endif
@@ -652,9 +726,25 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
         }
+        TL_MARK(5);
+#ifdef TVBF_DIAG_TIMELINE
+        ++tl_n;
+#endif
         ct = nct;
         kb = nkbi;
     }
+#ifdef TVBF_DIAG_TIMELINE
+    if (tl_on && lane == 0) {  // slot s = time from mark s-1 to mark s (slot 0: mark 5 -> mark 0)
+        unsigned long long* o = tl_buf + ((size_t)blockIdx.x * 4 + wave) * 16;
+        for (int i = 0; i < 6; ++i) o[i] = tl_sum[i];
+        o[6] = tl_n;
+        o[7] = (unsigned long long)tl_cnt[0] | ((unsigned long long)tl_cnt[1] << 32);
+        o[8] = (unsigned long long)tl_cnt[2] | ((unsigned long long)tl_cnt[3] << 32);
+        o[9] = tl_in[0];
+        o[10] = tl_in[1];
+        o[11] = tl_in[2];
+    }
+#endif
 
     if (MODE == MODE_STATS) {
         // every workgroup leaves its sums in its own slot (folded later in a fixed order) and
@@ -1234,6 +1324,9 @@ int tvbf_topk_accumulate_f32(const float* Zq, int64_t nq, int64_t q_row0, int64_
     a.col_tiles = tiles;
     a.min_similarity = min_similarity;
     a.exclude_self = exclude_self;
+#ifdef TVBF_DIAG_TIMELINE
+    if (const char* e = getenv("TVBF_DIAG_BUF")) a.gram = reinterpret_cast<float*>(strtoull(e, nullptr, 0));
+#endif
     if (list_global)
         hipLaunchKernelGGL(cosine_tile_kernel<MODE_TOPK_G>, dim3((unsigned)grid), dim3(TOPK_THREADS), p.lds_bytes,
                            (hipStream_t)stream, a);
