@@ -82,3 +82,34 @@ for lo in range(0, len(order), 1024):
     t5 = b[sel, :, 5].sum() / kb_
     sp = (raw[sel][..., 7] & 0xFFFFFFFF).sum() / (kb_ / (d / 32))
     print(f"  workgroups {lo:6d}+: epi {t5:7.1f} ticks per k-block, slow paths per tile {sp:.3f}, period {b[sel, :, :6].sum() / kb_:.0f}")
+
+# workgroup lifetimes on the 100 MHz wall clock: how busy are the 2 x CU slots, how long are start and end
+start = raw[:, :, 12].min(axis=1).astype(np.float64)
+end = raw[:, :, 15].max(axis=1).astype(np.float64)
+life = (end - start) / 100.0  # us
+span = (end.max() - start.min()) / 100.0
+loop_cycles = b[:, :, :6].sum(axis=2).max(axis=1)
+wave_cycles = raw[:, :, 13].astype(np.float64).max(axis=1)
+rate = (wave_cycles / (life * 1e-6)).mean()
+print(f"kernel span {span / 1e3:.2f} ms; workgroup lifetime mean {life.mean() / 1e3:.3f} ms; sum of lifetimes / (512 slots x span) = "
+      f"{life.sum() / (512 * span):.3f}")
+print(f"cycle counter rate {rate / 1e9:.3f} GHz; outside the k-block loop: {100 * (1 - loop_cycles.sum() / wave_cycles.sum()):.2f} % of a workgroup's cycles")
+hw = raw[:, 0, 14]
+cu = ((hw >> 32) << 20) | (hw & 0xFFFFFFFF) >> 8 & 0xFFF  # xcc, then cu_id / sh / se bits 8..19? keep 12 bits
+slots = {}
+for i in np.argsort(start):
+    slots.setdefault(int(cu[i]), []).append((start[i], end[i]))
+gaps = []
+for v in slots.values():
+    # two slots per CU: greedy assignment to measure idle time between successive workgroups
+    ends = []
+    for s_, e_ in v:
+        ends.sort()
+        if len(ends) >= 2:
+            gaps.append(s_ - ends[0])
+            ends[0] = e_
+        else:
+            ends.append(e_)
+if gaps:
+    g = np.array(gaps) / 100.0
+    print(f"{len(slots)} CUs seen; gap between a workgroup's end and its successor's start: mean {g.mean():.1f} us, p90 {np.percentile(g, 90):.1f} us")

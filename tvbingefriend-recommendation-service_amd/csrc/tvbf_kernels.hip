@@ -480,6 +480,7 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
 #ifdef TVBF_DIAG_TIMELINE  // timing-only build: every wave sums the cycle counter deltas between six marks
     unsigned long long* tl_buf = reinterpret_cast<unsigned long long*>(a.gram);
     unsigned long long tl_sum[6] = {0, 0, 0, 0, 0, 0}, tl_prev = 0, tl_n = 0;
+    const unsigned long long tl_start_rt = __builtin_amdgcn_s_memrealtime(), tl_start = __builtin_readcyclecounter();
     unsigned tl_cnt[4] = {0, 0, 0, 0};  // sub-tile slow paths, pop rounds, appended keys (lane 0..63 total), compactions
     unsigned long long tl_in[3] = {0, 0, 0}, tl_t0 = 0, tl_t1 = 0;  // cycles in slow paths, of these before the pop loop, in compactions
 #define TL_COUNT_EVENT(i, v) tl_cnt[i] += (v)
@@ -534,6 +535,10 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
 #else
 #define FRAG_LOAD(p) (*reinterpret_cast<const f32x4*>(p))
 #endif
+        // The first k-block of a tile starts its accumulators from the constant zero operand
+        // instead of clearing 64 registers in the epilogue (ordinary VALU work is expensive
+        // while the other resident wave streams MFMAs).
+        auto mfma_block = [&](const bool zero_first) __attribute__((always_inline)) {
         f32x4 qf = FRAG_LOAD(q_lds);
         f32x4 cf[NJ];
 #pragma unroll
@@ -554,9 +559,12 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    acc[j] = GRAM ? __builtin_amdgcn_mfma_f32_32x32x2f32(qf[i], cf[j][i], acc[j], 0, 0, 0)
-                                  : __builtin_amdgcn_mfma_f32_32x32x2f32(cf[j][i], qf[i], acc[j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j) {
+                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    const f32x16 c_in = (zero_first && t == 0 && i == 0) ? zero : acc[j];
+                    acc[j] = GRAM ? __builtin_amdgcn_mfma_f32_32x32x2f32(qf[i], cf[j][i], c_in, 0, 0, 0)
+                                  : __builtin_amdgcn_mfma_f32_32x32x2f32(cf[j][i], qf[i], c_in, 0, 0, 0);
+                }
             // pin the order: reads of step t+1 first, then the 4*NJ MFMAs of step t
             if (t < 3) __builtin_amdgcn_sched_group_barrier(0x100, NJ + 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 4 * NJ, 0);
@@ -564,6 +572,18 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
 #pragma unroll
             for (int j = 0; j < NJ; ++j) cf[j] = cn[j];
         }
+        };
+#ifndef TVBF_ZERO_FIRST
+#define TVBF_ZERO_FIRST 1
+#endif
+#if TVBF_ZERO_FIRST
+        if (kb == 0)
+            mfma_block(true);
+        else
+            mfma_block(false);
+#else
+        mfma_block(false);
+#endif
 
         TL_MARK(4);
         if (MODE == MODE_STATS && kb == nkb - 1) {
@@ -580,7 +600,6 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
                 for (int r = 0; r < 16; ++r) {
                     const int64_t qr = q0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                     const float v = acc[j][r];
-                    acc[j][r] = 0.f;
                     if (qr < c && c < n_cols) {
                         const unsigned key = f32_to_ordered(v);
                         if (a.st_level == 0) {
@@ -609,7 +628,6 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
                 for (int r = 0; r < 16; ++r) {
                     const int64_t qr = q0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                     if (qr < a.nq && c < n_cols) a.gram[qr * a.ldo + c] = acc[j][r];
-                    acc[j][r] = 0.f;
                 }
             }
         }
@@ -721,10 +739,6 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
                 }
             }
 #endif
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
         }
         TL_MARK(5);
 #ifdef TVBF_DIAG_TIMELINE
@@ -743,6 +757,10 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
         o[9] = tl_in[0];
         o[10] = tl_in[1];
         o[11] = tl_in[2];
+        o[12] = tl_start_rt;  // 100 MHz wall clock at workgroup start
+        o[13] = tl_start;     // cycle counter at start
+        o[14] = (unsigned long long)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 4) |
+                ((unsigned long long)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) << 32);
     }
 #endif
 
@@ -793,6 +811,14 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
         u64* dst = a.partial + ((int64_t)split * a.nq + qr) * a.k;
         for (int i = lane; i < a.k; i += 64) dst[i] = i < have ? buf_all[(size_t)row * a.cap + i] : empty;
     }
+#ifdef TVBF_DIAG_TIMELINE
+    if (tl_on && lane == 0) {
+        unsigned long long* o = tl_buf + ((size_t)blockIdx.x * 4 + wave) * 16;
+        o[15] = __builtin_amdgcn_s_memrealtime();  // 100 MHz wall clock at the end of the wave
+        o[5] += 0;
+        o[13] = __builtin_readcyclecounter() - o[13];  // cycles of the whole wave
+    }
+#endif
 }
 
 __global__ __launch_bounds__(256) void bound_init_kernel(unsigned* __restrict__ bound, int64_t nq, unsigned v) {
