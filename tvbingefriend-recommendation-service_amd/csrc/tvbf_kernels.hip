@@ -670,23 +670,33 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
 #else
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                float m = acc[j][0];
+                // Collect: one compare per accumulator register; a register in which some lane
+                // passes its row threshold queues those lanes' scores in the wave's scratch
+                // (slot = how many this lane has queued so far) and sets the lane's bit.  Ordinary
+                // VALU instructions are scarce while the other resident wave streams MFMAs, so
+                // the common case costs 16 compares and nothing else.
+                unsigned bits = 0u;
+                int queued = 0;
+#ifndef TVBF_DIAG_PRETEST_ONLY
 #pragma unroll
-                for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[j][r]);
-#ifdef TVBF_DIAG_PRETEST_ONLY  // timing-only build: the rejection test alone
-                asm volatile("" ::"v"(m));
-                if (false) {
+                for (int r = 0; r < 16; ++r) {
+                    if (acc[j][r] >= thr) {
+                        // the empty asm keeps a real branch around this block (skipped when no lane
+                        // passes) instead of running it with an all-zero execution mask
+                        asm volatile("");
+                        scratch[queued * 64 + lane] = acc[j][r];
+                        ++queued;
+                        bits |= 1u << r;
+                    }
+                }
 #else
-                if (__any(m >= thr)) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[j][r] >= thr ? 1 : 0));
 #endif
+                if (__any(bits != 0u)) {
                     TL_COUNT_EVENT(0, 1);
                     TL_BEGIN(tl_t0);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) scratch[r * 64 + lane] = acc[j][r];
-                    // which of this lane's 16 scores pass: a bit mask built from registers
-                    unsigned bits = 0u;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) bits |= acc[j][r] >= thr ? (1u << r) : 0u;
+                    int slot = 0;
                     TL_END(tl_t0, 1);
                     // one round per remaining candidate of the busiest lane
                     while (__any(bits != 0u)) {
@@ -694,7 +704,8 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
                         const bool has = bits != 0u;
                         const int r = has ? __builtin_ctz(bits) : 0;
                         bits &= bits - 1u;
-                        const float v = scratch[r * 64 + lane];
+                        const float v = scratch[slot * 64 + lane];  // queued in ascending register order
+                        ++slot;
                         const int c = (int)col0 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * half;
                         const u64 key = make_key(v, c);
                         bool cand = has && v >= thr && key > mkey;
