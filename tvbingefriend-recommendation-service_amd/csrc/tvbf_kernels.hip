@@ -855,19 +855,29 @@ __global__ __launch_bounds__(64 * FIN_ROWS) void topk_finalize_kernel(const u64*
     if (row >= nq) return;
     u64* b = buf[wave];
     const int m = splits * k;
-    for (int i = lane; i < m; i += 64) {
-        const int s = i / k;
-        b[i] = partial[((int64_t)s * nq + row) * k + (i - s * k)];
+    // gather the non-empty keys of all partial lists, packed (most slots of late splits are empty
+    // because the shared bound rejected their columns)
+    int packed = 0;
+    for (int i0 = 0; i0 < m; i0 += 64) {
+        const int i = i0 + lane;
+        u64 key = 0ull;
+        if (i < m) {
+            const int s = i / k;
+            key = partial[((int64_t)s * nq + row) * k + (i - s * k)];
+        }
+        const bool real = (uint32_t)key != 0u;
+        const u64 mask = __ballot(real);
+        if (real) b[packed + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = key;
+        packed += __builtin_popcountll(mask);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     int valid = 0;
-    for (int i = lane; i < m; i += 64) {
+    for (int i = lane; i < packed; i += 64) {
         const u64 me = b[i];
-        if ((uint32_t)me == 0u) continue;  // empty slot
         ++valid;
         int rank = 0;
-        for (int j = 0; j < m; ++j) rank += (b[j] > me) ? 1 : 0;
+        for (int j = 0; j < packed; ++j) rank += (b[j] > me) ? 1 : 0;
         if (rank < k) {
             out_idx[row * k + rank] = (int32_t)(0xFFFFFFFFu - (uint32_t)me);
             out_score[row * k + rank] = ordered_to_f32((uint32_t)(me >> 32));
@@ -886,6 +896,7 @@ __global__ __launch_bounds__(64 * FIN_ROWS) void topk_finalize_kernel(const u64*
 // --------------------------------------------------------------------------
 // K5: per-block cosines of the kept pairs.  One wavefront per (row, slot).
 // --------------------------------------------------------------------------
+template <bool VEC4>
 __global__ __launch_bounds__(256) void component_scores_kernel(const float* __restrict__ zq, int64_t nq,
                                                                const float* __restrict__ zall, int64_t n,
                                                                int64_t ld, BlockDesc bd,
@@ -905,7 +916,18 @@ __global__ __launch_bounds__(256) void component_scores_kernel(const float* __re
     const float* y = zall + (int64_t)j * ld;
     for (int b = 0; b < bd.nb; ++b) {
         float s = 0.f;
-        for (int c = bd.off[b] + lane; c < bd.off[b + 1]; c += 64) s = fmaf(x[c], y[c], s);
+        if (VEC4) {  // block starts and the row stride are multiples of 4 floats: 16-byte loads
+            for (int c = bd.off[b] + 4 * lane; c < bd.off[b + 1]; c += 256) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(x + c);
+                const f32x4 yv = *reinterpret_cast<const f32x4*>(y + c);
+                s = fmaf(xv[0], yv[0], s);
+                s = fmaf(xv[1], yv[1], s);
+                s = fmaf(xv[2], yv[2], s);
+                s = fmaf(xv[3], yv[3], s);
+            }
+        } else {
+            for (int c = bd.off[b] + lane; c < bd.off[b + 1]; c += 64) s = fmaf(x[c], y[c], s);
+        }
         s = wave_sum(s);
         const float w = bd.scale[b] * bd.scale[b];
         if (lane == 0) o[b] = w > 0.f ? s / w : 0.f;
@@ -1597,8 +1619,14 @@ int tvbf_component_scores_f32(const float* Zq, int64_t nq, const float* Zall, in
     if (nq == 0) return TVBF_OK;
     const int64_t grid = (nq * k + 3) / 4;
     if (grid > INT32_MAX) return fail(TVBF_E_BAD_ARG, "too many pairs");
-    hipLaunchKernelGGL(component_scores_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, Zq, nq,
-                       Zall, n, ld, bd, idx, k, out_comp);
+    bool vec4 = (ld & 3) == 0 && (((uintptr_t)Zq | (uintptr_t)Zall) & 15) == 0;
+    for (int b = 0; b <= nb; ++b) vec4 = vec4 && (block_offsets[b] & 3) == 0;
+    if (vec4)
+        hipLaunchKernelGGL(component_scores_kernel<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, Zq,
+                           nq, Zall, n, ld, bd, idx, k, out_comp);
+    else
+        hipLaunchKernelGGL(component_scores_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, Zq,
+                           nq, Zall, n, ld, bd, idx, k, out_comp);
     HIP_TRY(hipGetLastError());
     return TVBF_OK;
 }
