@@ -269,3 +269,19 @@ def test_wide_features_large_k_two_ranges(pkg, device):
     for o, r in enumerate(rows):
         check_topk_against_scores(h[o:o + 1], int(row0 + r), k, -1.0, idx[r:r + 1], score[r:r + 1],
                                   count[r:r + 1], what=f"wide row {r}")
+
+
+@pytest.mark.parametrize("k", [30, 31, 52, 53, 64, 99])
+def test_list_modes_agree_with_oracle_across_k(pkg, device, k):
+    """K = 30 | 31 is where the lists move from LDS to global memory: both sides of the boundary,
+    and larger K, against the float64 oracle on tie-free and on tie-rich data."""
+    n = 1500
+    x = dense_gaussian(n, 64, seed=100 + k)
+    top, _, _, _ = _run_topk(pkg, device, [x], [1.0], k, -1.0)
+    h, _ = _oracle_h([x], [1.0])
+    check_topk_against_scores(h, 0, k, -1.0, _to_np(top.idx), _to_np(top.score), _to_np(top.count), what=f"dense k={k}")
+    g, t, p, ty, la = hybrid_like_blocks(n, seed=k, d_genre=12, d_text=80)
+    blocks, weights = [g, t, np.hstack([p, ty, la])], [0.4, 0.5, 0.1]
+    top, _, _, _ = _run_topk(pkg, device, blocks, weights, k, 0.15)
+    h, _ = _oracle_h(blocks, weights)
+    check_topk_against_scores(h, 0, k, 0.15, _to_np(top.idx), _to_np(top.score), _to_np(top.count), what=f"hybrid k={k}")
