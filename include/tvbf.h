@@ -8,7 +8,8 @@
  *   tvbingefriend_recommendation_service/services/content_based_service.py:113-338.
  * Each entry point below names the reference lines whose arithmetic it
  * replaces.  A Python binding (ctypes) is what a maintainer of the reference
- * would add; see INTEGRATION.md.
+ * would add: load the library after `import torch` (one HIP runtime per process),
+ * declare restype/argtypes as below, pass tensor.data_ptr() for device pointers.
  *
  * Conventions
  *   - plain C, no C++ or torch types; every pointer marked "device" is a

@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <float.h>
+#include <type_traits>
 
 #include "tvbf.h"
 
@@ -832,6 +833,315 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
 #endif
 }
 
+// --------------------------------------------------------------------------
+// Fused top-K, tile loop with LDS-DMA (gfx950 global_load_lds_dwordx4).
+//
+// Same arithmetic and selection as cosine_tile_kernel<MODE_TOPK / MODE_TOPK_G> -- every
+// score is the same fixed-order fp32 chain, so the lists are bit-identical -- but the
+// operands travel differently:
+//   * the column tile goes global -> LDS directly, into the buffer the MFMAs are not
+//     reading (two 16 KiB buffers): no staging registers, no LDS write phase, and one
+//     barrier per k-block instead of two;
+//   * rows are stored unpadded (128 B) with the 16-byte chunk index XOR-ed with
+//     (row >> 1) & 7, which keeps the 16 rows of a ds_read_b128 lane group on 16
+//     different 16-byte bank slots;
+//   * the query fragments never touch LDS: a wave reads only its own 32 query rows, so
+//     each lane loads its 4 x 16 bytes of the next k-block straight into registers.
+// The epilogue's scratch is a separate 2 KiB per wave (eight queued scores per lane).
+// --------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void* global_cvoid_t;
+constexpr int DMA_SLOTS = 8;  // scores a lane can queue per collect pass
+
+template <bool LIST_GLOBAL>
+__global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkArgs a) {
+    static_assert(BK == 32 && BM == 128 && BN == 128, "the DMA tile loop is written for 128 x 128 x 32 tiles");
+    __shared__ __attribute__((aligned(16))) float tileC0[BN * BK];
+    __shared__ __attribute__((aligned(16))) float tileC1[BN * BK];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* buf_all = reinterpret_cast<u64*>(smem);                           // [BM][cap]
+    u64* mkey_all = buf_all + (size_t)BM * a.cap;                           // [BM]
+    unsigned* cnt_all = reinterpret_cast<unsigned*>(mkey_all + BM);        // [BM]
+    float* scratch_all = reinterpret_cast<float*>(cnt_all + BM);           // [4][DMA_SLOTS * 64]
+    u64* merge_scr = reinterpret_cast<u64*>(scratch_all + 4 * DMA_SLOTS * 64);  // [4][k + cap], global lists only
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: LDS-DMA bases are scalar
+    const int half = lane >> 5;
+    const int lrow = wave * 32 + (lane & 31);
+
+    const int rb = blockIdx.x % a.row_blocks;
+    const int split = blockIdx.x / a.row_blocks;
+    const int tile_begin = (int)(((int64_t)a.col_tiles * split) / a.splits);
+    const int tile_end = (int)(((int64_t)a.col_tiles * (split + 1)) / a.splits);
+    const int64_t q0 = (int64_t)rb * BM;
+
+    const bool dead_row = LIST_GLOBAL && q0 + lrow >= a.nq;
+    if (tid < BM) {
+        mkey_all[tid] = (LIST_GLOBAL && q0 + tid >= a.nq) ? ~0ull : sentinel_key(a.min_similarity);
+        cnt_all[tid] = 0u;
+    }
+    if (LIST_GLOBAL) {
+        int64_t rows = a.nq - (q0 + wave * 32);
+        rows = rows < 0 ? 0 : rows > 32 ? 32 : rows;
+        u64* g = a.partial + ((int64_t)split * a.nq + q0 + wave * 32) * a.k;
+        for (int64_t i = lane; i < rows * a.k; i += 64)
+            __hip_atomic_store(g + i, sentinel_key(a.min_similarity), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    }
+    u64* my_buf = buf_all + (size_t)lrow * a.cap;
+    u64* my_mkey = mkey_all + lrow;
+    unsigned* my_cnt = cnt_all + lrow;
+    u64 mkey = dead_row ? ~0ull : sentinel_key(a.min_similarity);
+    float thr = dead_row ? INFINITY : a.min_similarity;
+    float gbf = a.min_similarity;
+    unsigned* my_gb = (q0 + lrow < a.nq) ? a.bound + q0 + lrow : nullptr;
+    float* scratch = scratch_all + wave * (DMA_SLOTS * 64);
+
+    const int nkb = a.d / BK;
+    const int total = (tile_end - tile_begin) * nkb;
+
+    // ---- query fragments: lane = row lrow, 16 bytes at k = 8 t + 4 half of every 8-deep step ----
+    unsigned qoff;
+    {
+        int64_t r = lrow;
+        if (q0 + r > a.nq - 1) r = a.nq - 1 - q0;
+        qoff = (unsigned)((r * a.ld + half * 4) * 4);
+    }
+    // ---- column tile: thread t moves, in round i, the 16 bytes that land at LDS byte
+    // i*4096 + t*16 of the buffer = row i*32 + t/8, slot t%8; the slot holds chunk slot ^ swizzle ----
+    const int c_chunk = (tid & 7) ^ ((tid >> 4) & 7);  // (row >> 1) & 7 == (t >> 4) & 7 for every round
+    unsigned coff[4];
+    const char* tile_ptr = nullptr;  // first row of the current column tile (uniform)
+    auto set_tile = [&](int ct) {
+        const ColRange& cr = a.rng[ct >= a.rng[0].tiles ? 1 : 0];
+        const int64_t trow = (int64_t)(ct >= a.rng[0].tiles ? ct - a.rng[0].tiles : ct) * BN;
+        const int last = (int)(cr.n - 1 - trow < BN ? cr.n - 1 - trow : BN);  // rows past the range's end repeat its last row
+        {  // kept in scalar registers: the DMA instructions take a scalar base
+            const uint64_t p = reinterpret_cast<uint64_t>(cr.z + trow * a.ld);
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p);
+            const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+            tile_ptr = reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int r = i * 32 + (tid >> 3);
+            if (r > last) r = last;
+            coff[i] = (unsigned)(((unsigned)r * (unsigned)a.ld + c_chunk * 4) * 4);
+        }
+        asm volatile("" : "+v"(qoff));  // not a loop invariant for the compiler: keeps scalar base + 32-bit offset loads
+    };
+    auto dma_tile = [&](int kb, float* buffer) {
+        const char* cb = tile_ptr + (size_t)kb * (BK * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((global_cvoid_t)(cb + coff[i]),
+                                             (lds_void_t*)(buffer + i * 1024 + wave * 256), 16, 0, 0);
+    };
+    const char* qbase = reinterpret_cast<const char*>(a.zq + q0 * a.ld);
+    f32x4 qreg[2][4];
+    auto load_q = [&](int kb, f32x4(&q)[4]) {
+        const char* qb = qbase + (size_t)kb * (BK * 4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) q[t] = *reinterpret_cast<const f32x4*>(qb + qoff + t * 32);
+    };
+    // ---- fragment reads of the column tile: row (lane & 31) + 32 j, chunk 2 t + half ----
+    unsigned foff[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+        foff[t] = (unsigned)((lane & 31) * 128 + (((2 * t + half) ^ (((lane & 31) >> 1) & 7)) << 4));
+
+    f32x16 acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    // One k-block: the MFMAs of the tile in `cur` with the query fragments `q`; its transfers for the
+    // next k-block were issued by the caller.  Fragment reads run one 8-deep step ahead.
+    auto mfma_block = [&](const float* cur, const f32x4(&q)[4]) __attribute__((always_inline)) {
+        const char* cbytes = reinterpret_cast<const char*>(cur);
+        f32x4 cf[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) cf[j] = *reinterpret_cast<const f32x4*>(cbytes + foff[0] + j * 4096);
+        __builtin_amdgcn_sched_group_barrier(0x100, NJ, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x4 cn[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) cn[j] = cf[j];
+            if (t < 3) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) cn[j] = *reinterpret_cast<const f32x4*>(cbytes + foff[t + 1] + j * 4096);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(cf[j][i], q[t][i], acc[j], 0, 0, 0);
+            if (t < 3) __builtin_amdgcn_sched_group_barrier(0x100, NJ, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NJ, 0);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) cf[j] = cn[j];
+        }
+    };
+
+    if (tile_begin < tile_end) {
+        set_tile(tile_begin);
+        dma_tile(0, tileC0);
+        load_q(0, qreg[0]);
+    }
+    __syncthreads();  // lists initialised, first k-block in place
+
+    // k-blocks go in pairs (the host guarantees an even number per tile): A reads buffer 0 / set 0
+    // and fetches into buffer 1 / set 1, B the other way round.  A barrier ends every k-block: by
+    // then each wave's transfers have landed and each wave is done with the buffer it read.
+#pragma nounroll
+    for (int ct = tile_begin; ct < tile_end; ++ct) {
+        unsigned gb_bits = 0u;
+        if (my_gb) gb_bits = __hip_atomic_load(my_gb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma nounroll
+        for (int kb = 0; kb < nkb; kb += 2) {
+            dma_tile(kb + 1, tileC1);
+            load_q(kb + 1, qreg[1]);
+            __builtin_amdgcn_sched_barrier(0);  // the transfers leave before the MFMAs, not after them
+            mfma_block(tileC0, qreg[0]);
+            __syncthreads();
+            const bool last = kb + 2 >= nkb;
+            if (!last) {
+                dma_tile(kb + 2, tileC0);
+                load_q(kb + 2, qreg[0]);
+            } else if (ct + 1 < tile_end) {
+                set_tile(ct + 1);
+                dma_tile(0, tileC0);
+                load_q(0, qreg[0]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_block(tileC1, qreg[1]);
+            if (last) {
+                if (my_gb) {
+                    gbf = fmaxf(gbf, ordered_to_f32(gb_bits));
+                    thr = fmaxf(thr, gbf);
+                }
+            // ------------------------- epilogue (see cosine_tile_kernel) -------------------------
+            const ColRange& cr = a.rng[ct >= a.rng[0].tiles ? 1 : 0];
+            const int64_t trow = (int64_t)(ct >= a.rng[0].tiles ? ct - a.rng[0].tiles : ct) * BN;
+            const int64_t col0 = cr.col_base + trow;
+            const int64_t col_end = cr.col_base + cr.n;
+            const int64_t grow = a.q_row0 + q0 + lrow;
+            // columns are numbered inside the tile (0..127) for the two masks
+            if (col0 + BN > col_end) {  // past the end of the range (its last tile only)
+                int rel_end = (int)(col_end - col0) - 4 * half;
+                asm volatile("" : "+v"(rel_end));  // keeps the 64 compares here, not hoisted as 64 live masks
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (32 * j + (r & 3) + 8 * (r >> 2) >= rel_end) acc[j][r] = -INFINITY;
+            }
+            if (a.exclude_self && col0 < a.q_row0 + q0 + BM && col0 + BN > a.q_row0 + q0) {  // the show itself
+                const int64_t d_self = grow - col0;
+                int rel_self = (d_self >= 0 && d_self < BN) ? (int)d_self - 4 * half : -1000;
+                asm volatile("" : "+v"(rel_self));
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (32 * j + (r & 3) + 8 * (r >> 2) == rel_self) acc[j][r] = -INFINITY;
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+                for (int r0 = 0; r0 < 16; r0 += DMA_SLOTS) {
+                    unsigned bits = 0u;
+                    int queued = 0;
+#pragma unroll
+                    for (int r = r0; r < r0 + DMA_SLOTS; ++r) {
+                        if (acc[j][r] >= thr) {
+                            asm volatile("");  // keeps a real branch around the block
+                            scratch[queued * 64 + lane] = acc[j][r];
+                            ++queued;
+                            bits |= 1u << r;
+                        }
+                    }
+                    if (__any(bits != 0u)) {
+                        int slot = 0;
+                        while (__any(bits != 0u)) {
+                            const bool has = bits != 0u;
+                            const int r = has ? __builtin_ctz(bits) : 0;
+                            bits &= bits - 1u;
+                            const float v = scratch[slot * 64 + lane];
+                            ++slot;
+                            const int c = (int)col0 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * half;
+                            const u64 key = make_key(v, c);
+                            bool cand = has && v >= thr && key > mkey;
+                            while (__any(cand)) {
+                                if (cand) {
+                                    const unsigned pos = atomicAdd(my_cnt, 1u);
+                                    if (pos < (unsigned)a.cap) {
+                                        my_buf[pos] = key;
+                                        cand = false;
+                                    }
+                                }
+                                u64 full = __ballot(cand);
+                                if (full) {
+                                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                                    __builtin_amdgcn_wave_barrier();
+                                    while (full) {
+                                        const int l = (int)__builtin_ctzll(full) & 31;
+                                        const int row = wave * 32 + l;
+                                        const int64_t qr = q0 + row;
+                                        if (LIST_GLOBAL)
+                                            merge_row_global(buf_all + (size_t)row * a.cap, cnt_all + row, mkey_all + row,
+                                                             a.partial + ((int64_t)split * a.nq + qr) * a.k,
+                                                             merge_scr + (size_t)wave * (a.k + a.cap), a.k, a.cap, lane,
+                                                             a.bound + qr, sentinel_key(a.min_similarity));
+                                        else
+                                            compact_row(buf_all + (size_t)row * a.cap, cnt_all + row, mkey_all + row,
+                                                        a.k, a.cap, lane, qr < a.nq ? a.bound + qr : nullptr);
+                                        full &= ~((1ull << l) | (1ull << (l + 32)));
+                                    }
+                                    mkey = *my_mkey;
+                                    thr = fmaxf(ordered_to_f32((uint32_t)(mkey >> 32)), gbf);
+                                    cand = cand && v >= thr && key > mkey;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- final compaction and publication of this split's lists (per wave) ----
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const u64 empty = sentinel_key(a.min_similarity);
+#pragma nounroll
+    for (int l = 0; l < 32; ++l) {
+        const int row = wave * 32 + l;
+        const int64_t qr = q0 + row;
+        if (qr >= a.nq) break;
+        if (LIST_GLOBAL) {
+            merge_row_global(buf_all + (size_t)row * a.cap, cnt_all + row, mkey_all + row,
+                             a.partial + ((int64_t)split * a.nq + qr) * a.k,
+                             merge_scr + (size_t)wave * (a.k + a.cap), a.k, a.cap, lane, a.bound + qr, empty);
+            continue;
+        }
+        compact_row(buf_all + (size_t)row * a.cap, cnt_all + row, mkey_all + row, a.k, a.cap, lane, a.bound + qr);
+        const int have = (int)cnt_all[row];
+        u64* dst = a.partial + ((int64_t)split * a.nq + qr) * a.k;
+        for (int i = lane; i < a.k; i += 64) dst[i] = i < have ? buf_all[(size_t)row * a.cap + i] : empty;
+    }
+}
+
 __global__ __launch_bounds__(256) void bound_init_kernel(unsigned* __restrict__ bound, int64_t nq, unsigned v) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nq) bound[i] = v;
@@ -1170,23 +1480,36 @@ static bool topk_list_global(int k) {
     return k > 30;
 }
 
-static int topk_cap(int k) {
+// Which tile loop runs the fused top-K: the LDS-DMA loop (default) or the register-staged
+// loop of cosine_tile_kernel (TVBF_TILE_LOOP=staged; both give bit-identical lists).
+static bool topk_use_dma(int64_t d) {
+    if (d % (2 * BK)) return false;  // the DMA loop takes k-blocks in pairs
+    if (const char* e = getenv("TVBF_TILE_LOOP")) return strcmp(e, "staged") != 0;
+    return true;
+}
+
+static int topk_cap(int k, int64_t d) {
 #if TVBF_BN == 256
     if (k <= 20) return 24;  // keeps two workgroups per CU with the wider column tile
 #endif
     if (topk_list_global(k)) return 32;
+    if (topk_use_dma(d)) return k + 12 < 38 ? k + 12 : 38;  // 32 KiB of tiles + 8 KiB of scratch beside the lists
     if (k <= 30) return k + 12;
     if (k <= 52) return 64;
     return k + 12;
 }
 
-static size_t topk_lds_bytes(int k) {
+// dynamic LDS of the fused kernel (the DMA loop has 32 KiB of static tile buffers on top)
+static size_t topk_lds_bytes(int k, int64_t d) {
     size_t pad = 0;
     if (const char* e = getenv("TVBF_LDS_PAD")) pad = (size_t)atoi(e);  // tuning aid: forces one workgroup per CU
-    const size_t merge_scratch = topk_list_global(k) ? (size_t)4 * (k + topk_cap(k)) * 8 : 0;
-    return pad + (size_t)(BM + BN) * LDT * sizeof(float) + (size_t)BM * topk_cap(k) * 8 + (size_t)BM * 8 +
-           (size_t)BM * 4 + merge_scratch;
+    const size_t merge_scratch = topk_list_global(k) ? (size_t)4 * (k + topk_cap(k, d)) * 8 : 0;
+    const size_t lists = (size_t)BM * topk_cap(k, d) * 8 + (size_t)BM * 8 + (size_t)BM * 4 + merge_scratch;
+    if (topk_use_dma(d)) return pad + lists + (size_t)4 * DMA_SLOTS * 64 * sizeof(float);
+    return pad + (size_t)(BM + BN) * LDT * sizeof(float) + lists;
 }
+
+static size_t topk_static_lds_bytes(int64_t d) { return topk_use_dma(d) ? (size_t)2 * BN * BK * sizeof(float) : 0; }
 
 // Column splits trade tail balance (more, shorter workgroups) against repeated
 // list warm-up; every choice gives the same result because the merge applies
@@ -1195,8 +1518,8 @@ static Plan make_plan(int64_t nq, int col_tiles, int64_t d, int k, int cus, int 
     Plan p;
     p.row_blocks = (int)((nq + BM - 1) / BM);
     p.col_tiles = col_tiles;
-    p.lds_bytes = topk_lds_bytes(k);
-    p.wg_per_cu = p.lds_bytes * 2 <= 160 * 1024 ? 2 : 1;
+    p.lds_bytes = topk_lds_bytes(k, d);
+    p.wg_per_cu = (p.lds_bytes + topk_static_lds_bytes(d)) * 2 <= 160 * 1024 ? 2 : 1;
     const int64_t slots = (int64_t)cus * p.wg_per_cu;
     int max_s = max_slots;
     if (max_s > 16) max_s = 16;
@@ -1359,10 +1682,13 @@ int tvbf_topk_accumulate_f32(const float* Zq, int64_t nq, int64_t q_row0, int64_
     if (workspace_bytes < need) return fail(TVBF_E_BAD_SHAPE, "workspace must be >= %zu bytes", need);
     const int64_t grid = (int64_t)p.row_blocks * p.splits;
     if (grid > INT32_MAX) return fail(TVBF_E_BAD_ARG, "too many workgroups");
-    const bool list_global = topk_list_global(k);
-    const void* kernel = list_global ? reinterpret_cast<const void*>(cosine_tile_kernel<MODE_TOPK_G>)
-                                     : reinterpret_cast<const void*>(cosine_tile_kernel<MODE_TOPK>);
-    if (p.lds_bytes > 48 * 1024)
+    const bool list_global = topk_list_global(k), dma = topk_use_dma(d);
+    const void* kernel =
+        dma ? (list_global ? reinterpret_cast<const void*>(cosine_topk_dma_kernel<true>)
+                           : reinterpret_cast<const void*>(cosine_topk_dma_kernel<false>))
+            : (list_global ? reinterpret_cast<const void*>(cosine_tile_kernel<MODE_TOPK_G>)
+                           : reinterpret_cast<const void*>(cosine_tile_kernel<MODE_TOPK>));
+    if (p.lds_bytes > 32 * 1024)
         HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
     TopkArgs a;
     memset(&a, 0, sizeof(a));
@@ -1377,7 +1703,7 @@ int tvbf_topk_accumulate_f32(const float* Zq, int64_t nq, int64_t q_row0, int64_
     a.ld = ld;
     a.d = (int)d;
     a.k = k;
-    a.cap = topk_cap(k);
+    a.cap = topk_cap(k, d);
     a.row_blocks = p.row_blocks;
     a.splits = p.splits;
     a.col_tiles = tiles;
@@ -1386,7 +1712,13 @@ int tvbf_topk_accumulate_f32(const float* Zq, int64_t nq, int64_t q_row0, int64_
 #ifdef TVBF_DIAG_TIMELINE
     if (const char* e = getenv("TVBF_DIAG_BUF")) a.gram = reinterpret_cast<float*>(strtoull(e, nullptr, 0));
 #endif
-    if (list_global)
+    if (dma && list_global)
+        hipLaunchKernelGGL(cosine_topk_dma_kernel<true>, dim3((unsigned)grid), dim3(TOPK_THREADS), p.lds_bytes,
+                           (hipStream_t)stream, a);
+    else if (dma)
+        hipLaunchKernelGGL(cosine_topk_dma_kernel<false>, dim3((unsigned)grid), dim3(TOPK_THREADS), p.lds_bytes,
+                           (hipStream_t)stream, a);
+    else if (list_global)
         hipLaunchKernelGGL(cosine_tile_kernel<MODE_TOPK_G>, dim3((unsigned)grid), dim3(TOPK_THREADS), p.lds_bytes,
                            (hipStream_t)stream, a);
     else
