@@ -277,7 +277,7 @@ def main():
         "topk_build_time_s": elapsed / args.steps,
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                     "kernel": "cosine_tile_kernel<0> (HIP events also span the 4 us bound fill and the "
+                     "kernel": "cosine_topk_dma_kernel<false> (HIP events also span the 4 us bound fill and the "
                                "0.3 ms list merge of the same call)", "kernel_ms": kernel_avg_ms},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

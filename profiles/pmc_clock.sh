@@ -14,11 +14,11 @@ cc = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
 kt = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
 dur = {}
 for r in csv.DictReader(open(kt)):
-    if "cosine_tile" in r["Kernel_Name"]:
+    if ("cosine_tile" in r["Kernel_Name"] or "cosine_topk_dma" in r["Kernel_Name"]):
         dur[r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
 vals = collections.defaultdict(dict)
 for r in csv.DictReader(open(cc)):
-    if "cosine_tile" in r["Kernel_Name"]:
+    if ("cosine_tile" in r["Kernel_Name"] or "cosine_topk_dma" in r["Kernel_Name"]):
         vals[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
 for k, v in vals.items():
     t = dur.get(k)

@@ -14,7 +14,7 @@ tag = sys.argv[1]
 root = Path(__file__).resolve().parent.parent
 pmc = root / "gpurun_out" / f"pmc_{tag}"
 stats = root / "gpurun_out" / f"stats_{tag}"
-KERNEL = "cosine_tile_kernel<0>"
+KERNEL = "cosine_topk_dma_kernel<false>"
 res = {}
 for name in ("sq1", "sq2", "tcc1", "tcc2"):
     f = glob.glob(f"{pmc}/{name}/**/*counter_collection.csv", recursive=True)

@@ -285,3 +285,33 @@ def test_list_modes_agree_with_oracle_across_k(pkg, device, k):
     top, _, _, _ = _run_topk(pkg, device, blocks, weights, k, 0.15)
     h, _ = _oracle_h(blocks, weights)
     check_topk_against_scores(h, 0, k, 0.15, _to_np(top.idx), _to_np(top.score), _to_np(top.count), what=f"hybrid k={k}")
+
+
+@pytest.mark.parametrize("n,d,k,ms", [(3000, 256, 20, 0.1), (1111, 64, 50, -1.0), (5000, 1024, 20, 0.1), (700, 192, 100, -1.0)])
+def test_both_tile_loops_give_identical_lists(pkg, device, monkeypatch, n, d, k, ms):
+    """The LDS-DMA tile loop and the register-staged loop are two schedules of the same fixed-order
+    arithmetic: indices, scores and counts must agree bit for bit (and match the oracle)."""
+    import torch
+
+    from tvbingefriend_recommendation_service_amd import engine
+
+    if ms > 0:
+        g, t, p, ty, la = hybrid_like_blocks(n, seed=n, d_genre=32, d_text=d - 64)
+        blocks, weights = [g, t, np.hstack([p, ty, la])], [0.4, 0.5, 0.1]
+    else:
+        blocks, weights = [dense_gaussian(n, d, seed=n + d)], [1.0]
+    x = np.ascontiguousarray(np.hstack([np.asarray(b, dtype=np.float32) for b in blocks]))
+    offsets = np.concatenate([[0], np.cumsum([b.shape[1] for b in blocks])]).astype(int).tolist()
+    z = engine.normalize_blocks(torch.from_numpy(x).to(device), offsets, [float(np.sqrt(w)) for w in weights])
+    assert z.shape[1] % 64 == 0  # otherwise only the staged loop can run
+    results = {}
+    for loop in ("dma", "staged"):
+        monkeypatch.setenv("TVBF_TILE_LOOP", loop)
+        top = engine.cosine_topk(z, k, ms)
+        torch.cuda.synchronize()
+        results[loop] = (_to_np(top.idx), _to_np(top.score), _to_np(top.count))
+    monkeypatch.delenv("TVBF_TILE_LOOP")
+    for a_, b_ in zip(results["dma"], results["staged"]):
+        assert np.array_equal(a_, b_)
+    h, _ = _oracle_h(blocks, weights)
+    check_topk_against_scores(h, 0, k, ms, *results["dma"], what=f"tile loops {n}x{d}")

@@ -1007,6 +1007,9 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
             load_q(kb + 1, qreg[1]);
             __builtin_amdgcn_sched_barrier(0);  // the transfers leave before the MFMAs, not after them
             mfma_block(tileC0, qreg[0]);
+            // all 64 MFMAs are issued before the wait for this k-block's transfers (the compiler
+            // would otherwise sink half of them below the barrier and wait for memory too early)
+            __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
             const bool last = kb + 2 >= nkb;
             if (!last) {
@@ -1116,6 +1119,7 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
             }
+            __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
         }
     }
