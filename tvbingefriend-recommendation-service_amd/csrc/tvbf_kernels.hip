@@ -935,16 +935,21 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
     auto dma_tile = [&](int kb, float* buffer) {
         const char* cb = tile_ptr + (size_t)kb * (BK * 4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((global_cvoid_t)(cb + coff[i]),
+        for (int i = 0; i < 4; ++i) {
+            unsigned off = coff[i];
+            asm volatile("" : "+v"(off));  // the widening to 64 bits stays next to the use: scalar base + 32-bit offset
+            __builtin_amdgcn_global_load_lds((global_cvoid_t)(cb + off),
                                              (lds_void_t*)(buffer + i * 1024 + wave * 256), 16, 0, 0);
+        }
     };
     const char* qbase = reinterpret_cast<const char*>(a.zq + q0 * a.ld);
     f32x4 qreg[2][4];
     auto load_q = [&](int kb, f32x4(&q)[4]) {
         const char* qb = qbase + (size_t)kb * (BK * 4);
+        unsigned off = qoff;
+        asm volatile("" : "+v"(off));
 #pragma unroll
-        for (int t = 0; t < 4; ++t) q[t] = *reinterpret_cast<const f32x4*>(qb + qoff + t * 32);
+        for (int t = 0; t < 4; ++t) q[t] = *reinterpret_cast<const f32x4*>(qb + off + t * 32);
     };
     // ---- fragment reads of the column tile: row (lane & 31) + 32 j, chunk 2 t + half ----
     unsigned foff[4];
@@ -1012,13 +1017,11 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
             const bool last = kb + 2 >= nkb;
-            if (!last) {
-                dma_tile(kb + 2, tileC0);
-                load_q(kb + 2, qreg[0]);
-            } else if (ct + 1 < tile_end) {
-                set_tile(ct + 1);
-                dma_tile(0, tileC0);
-                load_q(0, qreg[0]);
+            if (!last || ct + 1 < tile_end) {  // one issue site for "next k-block" and "first k-block of the next tile"
+                if (last) set_tile(ct + 1);
+                const int next_kb = last ? 0 : kb + 2;
+                dma_tile(next_kb, tileC0);
+                load_q(next_kb, qreg[0]);
             }
             __builtin_amdgcn_sched_barrier(0);
             mfma_block(tileC1, qreg[1]);
