@@ -131,7 +131,8 @@ size_t tvbf_topk_workspace_bytes(int64_t nq, int64_t n, int64_t d, int k);
  *   Zq          device, nq x d fp32, row stride ld (normally Zall + q_row0*ld)
  *   q_row0      global row index of Zq[0] (for self exclusion; rows of a shard)
  *   Zall        device, n x d fp32, row stride ld
- *   d           multiple of 32 (pad with zero columns; tvbf_normalize_blocks_f32 zero-fills)
+ *   d           multiple of 32 (pad with zero columns; tvbf_normalize_blocks_f32 zero-fills);
+ *               multiples of 64 run the faster LDS-DMA tile loop, with identical results
  *   ld          multiple of 4 (16-byte aligned rows); pointers 16-byte aligned
  *   k           1..TVBF_MAX_K
  *   out_idx     device, nq x k int32, unused slots = -1
