@@ -146,6 +146,27 @@ int tvbf_cosine_topk_f32(const float* Zq, int64_t nq, int64_t q_row0, const floa
                          size_t workspace_bytes, void* stream);
 
 /*
+ * The whole-catalogue case of tvbf_cosine_topk_f32 (Zq == Zall, nq == n, q_row0 == 0:
+ * ml/similarity_computer.py:122-124 followed by :159-166 for every show, or the loop of
+ * scripts/populate_database.py:170-218 over all shows) computing every pair of shows ONCE.
+ * score(i, j) and score(j, i) are the same products summed in the same order, so the score
+ * matrix is symmetric bit for bit and the result equals tvbf_cosine_topk_f32's exactly; only
+ * about half of it (plus 1/16 for seeding the bounds) is computed.
+ *
+ *   d           multiple of 64;  k <= 24 (the lists and the column queue share LDS);
+ *               n large enough for two shards of 128-row blocks
+ *   workspace   >= tvbf_cosine_topk_sym_workspace_bytes(n, d, k) bytes, which returns 0 when
+ *               the shape is not taken (call tvbf_cosine_topk_f32 then)
+ * Every show has a buffer of 512 column-side candidates; should one overflow (hundreds of exact
+ * ties at a show's K-th score), the call recomputes the plain way on the device, without host
+ * synchronisation -- correct, at the plain sweep's cost on top.
+ */
+size_t tvbf_cosine_topk_sym_workspace_bytes(int64_t n, int64_t d, int k);
+int tvbf_cosine_topk_sym_f32(const float* Z, int64_t n, int64_t d, int64_t ld, int k, float min_similarity,
+                             int exclude_self, int32_t* out_idx, float* out_score, int32_t* out_count,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * Incremental form of tvbf_cosine_topk_f32 for callers that receive the columns
  * in pieces -- a row shard of a multi-GPU job scores its own rows against its
  * own shard while the all-gather of the other shards is still in flight, then

@@ -320,3 +320,40 @@ def test_populate_columnar_sink_equals_dict_sink(pkg, device, tmp_path):
             for sid, items in dict_sink.records.items() for r in items]
     rows = [row for batch in col_sink.rows(1000) for row in batch]
     assert rows == flat
+
+
+def test_rccl_route_one_rank_group(pkg, device):
+    """The collective route of sharded_topk (asynchronous all_gather_into_tensor over RCCL, own
+    columns scored meanwhile, the rest after work.wait()) on a one-rank process group: the lists
+    equal the plain single-sweep result bit for bit."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from tvbingefriend_recommendation_service_amd import engine, sharding
+
+    n, k, ms = 3000, 20, 0.1
+    g, t, p, ty, la = hybrid_like_blocks(n, seed=77, d_genre=16, d_text=208)
+    x = torch.from_numpy(np.ascontiguousarray(np.hstack([g, t, p, ty, la]), dtype=np.float32)).to(device)
+    offsets, scales = [0, 16, 224, 256], [float(np.sqrt(w)) for w in (0.4, 0.5, 0.1)]
+    want = engine.cosine_topk(engine.normalize_blocks(x, offsets, scales), k, ms)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    assert not dist.is_initialized()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=device)
+    try:
+        sh = sharding.shard_bounds(n, 1, 0)
+        for _ in range(3):  # repeated steps reuse the communicator
+            top, z_all = sharding.sharded_topk(x, offsets, scales, sh, k, ms, collective=True)
+            torch.cuda.synchronize()
+            assert z_all.shape[0] == n
+            assert torch.equal(top.idx, want.idx) and torch.equal(top.score, want.score)
+            assert torch.equal(top.count, want.count)
+        flag = torch.tensor([3.0], dtype=torch.float64, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)  # the reduction bench.py uses for its timings
+        assert float(flag.item()) == 3.0
+    finally:
+        dist.destroy_process_group()

@@ -1,0 +1,158 @@
+"""GPU tests of the symmetric whole-catalogue sweep: every pair of shows computed once, lists
+equal to the plain sweep's bit for bit (and the plain sweep is checked against the oracle in
+test_gpu_topk.py), here once more against the float64 oracle directly."""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from oracle import similarity_oracle as so
+from parity import check_topk_against_scores
+from synth import dense_gaussian, hybrid_like_blocks
+
+pytestmark = pytest.mark.gpu
+
+
+def _to_np(t):
+    return t.detach().cpu().numpy()
+
+
+def _z_hybrid(device, n, seed, d_genre=16, d_text=208):
+    import torch
+
+    from tvbingefriend_recommendation_service_amd import engine
+
+    g, t, p, ty, la = hybrid_like_blocks(n, seed=seed, d_genre=d_genre, d_text=d_text)
+    x = np.ascontiguousarray(np.hstack([g, t, p, ty, la]), dtype=np.float32)
+    offsets = [0, d_genre, d_genre + d_text, x.shape[1]]
+    scales = [float(np.sqrt(w)) for w in (0.4, 0.5, 0.1)]
+    return engine.normalize_blocks(torch.from_numpy(x).to(device), offsets, scales), x, offsets
+
+
+def _assert_same(a, b, what):
+    assert np.array_equal(_to_np(a.count), _to_np(b.count)), what
+    assert np.array_equal(_to_np(a.idx), _to_np(b.idx)), what
+    assert np.array_equal(_to_np(a.score), _to_np(b.score)), what
+
+
+@pytest.mark.parametrize("n,shards", [(1500, 16), (1500, 5), (1500, 3), (1500, 2), (2049, 4), (2049, 7), (4000, 16)])
+def test_symmetric_equals_plain_hybrid(pkg, device, monkeypatch, n, shards):
+    """Odd and even shard counts, ragged last shard and last tile: identical lists."""
+    import torch
+
+    from tvbingefriend_recommendation_service_amd import engine
+
+    monkeypatch.setenv("TVBF_SYM_SHARDS", str(shards))
+    z, _, _ = _z_hybrid(device, n, seed=200 + n)
+    assert z.shape[1] % 64 == 0
+    for k, ms in ((20, 0.1), (7, 0.3)):
+        plain = engine.cosine_topk(z, k, ms)
+        sym = engine.cosine_topk_symmetric(z, k, ms)
+        torch.cuda.synchronize()
+        _assert_same(sym, plain, f"n={n} shards={shards} k={k}")
+
+
+@pytest.mark.parametrize("n,d,k", [(1300, 64, 24), (3000, 128, 20), (1025, 192, 1)])
+def test_symmetric_dense_against_oracle(pkg, device, n, d, k):
+    """No min_similarity cut, negative scores in the lists: against the float64 oracle and the plain sweep."""
+    import torch
+
+    from tvbingefriend_recommendation_service_amd import engine
+
+    x = dense_gaussian(n, d, seed=77 + n)
+    z = engine.normalize_blocks(torch.from_numpy(x).to(device), [0, d], [1.0])
+    sym = engine.cosine_topk_symmetric(z, k, -1.0)
+    plain = engine.cosine_topk(z, k, -1.0)
+    torch.cuda.synchronize()
+    _assert_same(sym, plain, f"dense {n}x{d}")
+    zo = so.build_z([x.astype(np.float64)], [1.0])
+    check_topk_against_scores(zo @ zo.T, 0, k, -1.0, _to_np(sym.idx), _to_np(sym.score), _to_np(sym.count),
+                              what=f"symmetric dense {n}x{d} k={k}")
+
+
+def test_symmetric_keeps_self_when_asked(pkg, device):
+    import torch
+
+    from tvbingefriend_recommendation_service_amd import engine
+
+    z, _, _ = _z_hybrid(device, 1800, seed=9)
+    sym = engine.cosine_topk_symmetric(z, 10, 0.1, exclude_self=False)
+    plain = engine.cosine_topk(z, 10, 0.1, exclude_self=False)
+    torch.cuda.synchronize()
+    _assert_same(sym, plain, "exclude_self=False")
+    # nearly every show leads its own list (identical twins with a lower index come first)
+    assert (_to_np(sym.idx)[:, 0] == np.arange(1800)).mean() > 0.9
+
+
+def test_symmetric_overflow_recomputes_plainly(pkg, device, monkeypatch):
+    """Column buffers of two entries overflow at once: the gated plain sweep takes over on the
+    device and the lists are still exact."""
+    import torch
+
+    from tvbingefriend_recommendation_service_amd import engine
+
+    z, _, _ = _z_hybrid(device, 1700, seed=31)
+    plain = engine.cosine_topk(z, 20, 0.1)
+    monkeypatch.setenv("TVBF_SYM_COL_CAP", "2")
+    sym = engine.cosine_topk_symmetric(z, 20, 0.1)
+    torch.cuda.synchronize()
+    _assert_same(sym, plain, "overflow")
+
+
+def test_symmetric_with_cliques_of_identical_shows(pkg, device):
+    """Groups of identical rows (exact ties at score 1 and at every other score): ties are
+    resolved by column index on both sides exactly as in the plain sweep."""
+    import torch
+
+    from tvbingefriend_recommendation_service_amd import engine
+
+    rng = np.random.default_rng(5)
+    base = dense_gaussian(60, 128, seed=3)
+    x = base[rng.integers(0, 60, size=2500)]  # about 40 copies of each of 60 shows
+    z = engine.normalize_blocks(torch.from_numpy(np.ascontiguousarray(x)).to(device), [0, 128], [1.0])
+    for k in (5, 20):
+        sym = engine.cosine_topk_symmetric(z, k, -1.0)
+        plain = engine.cosine_topk(z, k, -1.0)
+        torch.cuda.synchronize()
+        _assert_same(sym, plain, f"cliques k={k}")
+
+
+def test_symmetric_shape_limits(pkg, device):
+    import torch
+
+    from tvbingefriend_recommendation_service_amd import engine
+
+    assert engine.symmetric_workspace_bytes(100_000, 1024, 20) > 0
+    assert engine.symmetric_workspace_bytes(100_000, 1024 + 32, 20) == 0  # row length must be a multiple of 64
+    assert engine.symmetric_workspace_bytes(100_000, 1024, 50) == 0       # lists and queue would not fit LDS
+    assert engine.symmetric_workspace_bytes(100, 64, 5) == 0              # a single row block
+    z = torch.zeros((100, 64), device=device)
+    with pytest.raises(ValueError):
+        engine.cosine_topk_symmetric(z, 5, 0.0)
+
+
+def test_symmetric_benchmark_shape_sample(pkg, device):
+    """N = 100k x D = 1024, K = 20: equal to the plain sweep on every row (bitwise)."""
+    import torch
+
+    from tvbingefriend_recommendation_service_amd import engine
+
+    n, d, k, ms = 100_000, 1024, 20, 0.1
+    gen = torch.Generator(device=device)
+    gen.manual_seed(6)
+    x = torch.zeros((n, d), device=device)
+    x[:, :32] = (torch.rand((n, 32), generator=gen, device=device) < 0.08).float()
+    text = torch.randn((n, d - 64), generator=gen, device=device).abs_()
+    text *= torch.rand((n, d - 64), generator=gen, device=device) < 0.03
+    x[:, 32 : d - 32] = text
+    del text
+    x[torch.arange(n, device=device), d - 32 + torch.randint(0, 32, (n,), generator=gen, device=device)] = 1.0
+    z = engine.normalize_blocks(x, [0, 32, d - 32, d], [float(np.sqrt(w)) for w in (0.4, 0.5, 0.1)])
+    del x
+    sym = engine.cosine_topk_symmetric(z, k, ms)
+    plain = engine.cosine_topk(z, k, ms)
+    torch.cuda.synchronize()
+    assert torch.equal(sym.count, plain.count)
+    assert torch.equal(sym.idx, plain.idx)
+    assert torch.equal(sym.score, plain.score)

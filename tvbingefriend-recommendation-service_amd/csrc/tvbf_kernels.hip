@@ -168,6 +168,17 @@ struct TopkArgs {
     unsigned* st_hist;          // [2][ST_BINS] radix histograms of the two median ranks
     const unsigned* st_prefix;  // [2] key prefixes selected by the earlier levels
     int st_level, st_chunk;     // radix level 0..2; column tiles per workgroup
+    // symmetric sweep (query rows and columns are the same matrix, given whole as rng[0]): the row
+    // blocks form `shards` groups of sh_blocks; the kernel derives each group's column ranges
+    int sh_blocks, shards;
+    // column side of a tile: a score that reaches the bound of its COLUMN's show is appended to
+    // that show's buffer -- the pair is then never computed with the roles swapped
+    const unsigned* col_bound;  // [shows] lower bounds of the K-th scores (ordered bits), by global row
+    unsigned* col_cnt;          // [shows] entries appended (may exceed col_cap: the rest was dropped)
+    u64* col_buf;               // [shows][col_cap] keys (score, global row of the QUERY side)
+    int col_cap, col_lds;       // entries per show; entries of the workgroup's LDS queue
+    unsigned* overflow;         // set to 1 when a show's buffer was full
+    const unsigned* gate;       // plain sweeps: skip all work unless *gate != 0 (null: always run)
 };
 
 // radix select of the median over ordered 32-bit keys: 11 + 11 + 10 bits
@@ -853,9 +864,31 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void* global_cvoid_t;
 constexpr int DMA_SLOTS = 8;  // scores a lane can queue per collect pass
 
-template <bool LIST_GLOBAL>
+// SYM selects the column ranges and the column side:
+//   SYM_OFF    ranges as given, row side only (the general sweep);
+//   SYM_DIAG   each shard of row blocks against its own columns, row side only: seeds the bounds;
+//   SYM_HALF   each shard against the (shards - 1) / 2 shards that follow it cyclically (for an
+//              even count the pairs at distance shards / 2 go to the lower shard), both sides:
+//              every pair of different shards is computed once.
+// Scores are symmetric BIT FOR BIT -- score(i, j) and score(j, i) are the same products summed in
+// the same order -- so handing a tile's scores to the column shows gives them exactly the
+// candidates their own sweep would have found.
+enum { SYM_OFF = 0, SYM_DIAG = 1, SYM_HALF = 2 };
+
+__device__ static inline void col_append(const TopkArgs& a, unsigned rowg, u64 key) {
+    const unsigned p = atomicAdd(a.col_cnt + rowg, 1u);
+    if (p < (unsigned)a.col_cap)
+        a.col_buf[(int64_t)rowg * a.col_cap + p] = key;
+    else
+        __hip_atomic_store(a.overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool LIST_GLOBAL, int SYM = SYM_OFF>
 __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkArgs a) {
     static_assert(BK == 32 && BM == 128 && BN == 128, "the DMA tile loop is written for 128 x 128 x 32 tiles");
+    static_assert(SYM == SYM_OFF || !LIST_GLOBAL, "the symmetric sweeps keep their lists in LDS");
+    constexpr bool COLSIDE = SYM == SYM_HALF;
+    if (SYM == SYM_OFF && a.gate && __hip_atomic_load(a.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
     __shared__ __attribute__((aligned(16))) float tileC0[BN * BK];
     __shared__ __attribute__((aligned(16))) float tileC1[BN * BK];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -864,6 +897,11 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
     unsigned* cnt_all = reinterpret_cast<unsigned*>(mkey_all + BM);        // [BM]
     float* scratch_all = reinterpret_cast<float*>(cnt_all + BM);           // [4][DMA_SLOTS * 64]
     u64* merge_scr = reinterpret_cast<u64*>(scratch_all + 4 * DMA_SLOTS * 64);  // [4][k + cap], global lists only
+    // column side (same place as merge_scr, which only the global lists use)
+    float* cbound = scratch_all + 4 * DMA_SLOTS * 64;                      // [BN] bounds of the tile's column shows
+    unsigned* lcnt = reinterpret_cast<unsigned*>(cbound + BN);             // entries queued (4 words reserved)
+    u64* lkey = reinterpret_cast<u64*>(lcnt + 4);                          // [col_lds]
+    unsigned* lrowg = reinterpret_cast<unsigned*>(lkey + (COLSIDE ? a.col_lds : 0));  // [col_lds]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -873,8 +911,38 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
 
     const int rb = blockIdx.x % a.row_blocks;
     const int split = blockIdx.x / a.row_blocks;
-    const int tile_begin = (int)(((int64_t)a.col_tiles * split) / a.splits);
-    const int tile_end = (int)(((int64_t)a.col_tiles * (split + 1)) / a.splits);
+    ColRange rng0 = a.rng[0], rng1 = a.rng[1];
+    int col_tiles = a.col_tiles;
+    if (SYM != SYM_OFF) {
+        const int64_t shard_rows = (int64_t)a.sh_blocks * BM, n_all = a.rng[0].n;
+        const float* z_all = a.rng[0].z;
+        const int64_t ld = a.ld;
+        auto span = [=](int first, int count) {  // shards [first, first + count), count >= 0, no wrap
+            const int64_t r0 = first * shard_rows;
+            int64_t r1 = (first + count) * shard_rows;
+            if (r1 > n_all) r1 = n_all;
+            return ColRange{z_all + r0 * ld, r1 - r0, r0, (int)((r1 - r0 + BN - 1) / BN)};
+        };
+        const int v = rb / a.sh_blocks, V = a.shards;
+        if (SYM == SYM_DIAG) {
+            rng0 = span(v, 1);
+            rng1 = span(0, 0);
+        } else {
+            int h = (V - 1) / 2;
+            if (!(V & 1) && v < V / 2) ++h;
+            const int s0 = v + 1 >= V ? 0 : v + 1;
+            if (s0 + h <= V) {
+                rng0 = span(s0, h);
+                rng1 = span(0, 0);
+            } else {
+                rng0 = span(s0, V - s0);
+                rng1 = span(0, s0 + h - V);
+            }
+        }
+        col_tiles = rng0.tiles + rng1.tiles;
+    }
+    const int tile_begin = (int)(((int64_t)col_tiles * split) / a.splits);
+    const int tile_end = (int)(((int64_t)col_tiles * (split + 1)) / a.splits);
     const int64_t q0 = (int64_t)rb * BM;
 
     const bool dead_row = LIST_GLOBAL && q0 + lrow >= a.nq;
@@ -882,6 +950,7 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
         mkey_all[tid] = (LIST_GLOBAL && q0 + tid >= a.nq) ? ~0ull : sentinel_key(a.min_similarity);
         cnt_all[tid] = 0u;
     }
+    if (COLSIDE && tid == 0) *lcnt = 0u;
     if (LIST_GLOBAL) {
         int64_t rows = a.nq - (q0 + wave * 32);
         rows = rows < 0 ? 0 : rows > 32 ? 32 : rows;
@@ -914,10 +983,16 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
     const int c_chunk = (tid & 7) ^ ((tid >> 4) & 7);  // (row >> 1) & 7 == (t >> 4) & 7 for every round
     unsigned coff[4];
     const char* tile_ptr = nullptr;  // first row of the current column tile (uniform)
+    unsigned cb_bits = 0u;           // column side: bound of column show tid of the tile set last
     auto set_tile = [&](int ct) {
-        const ColRange& cr = a.rng[ct >= a.rng[0].tiles ? 1 : 0];
-        const int64_t trow = (int64_t)(ct >= a.rng[0].tiles ? ct - a.rng[0].tiles : ct) * BN;
+        const ColRange& cr = ct >= rng0.tiles ? rng1 : rng0;
+        const int64_t trow = (int64_t)(ct >= rng0.tiles ? ct - rng0.tiles : ct) * BN;
         const int last = (int)(cr.n - 1 - trow < BN ? cr.n - 1 - trow : BN);  // rows past the range's end repeat its last row
+        if (COLSIDE) {
+            cb_bits = 0xFF800000u;  // +inf: nothing is accepted for rows past the range's end
+            if (tid < BN && trow + tid < cr.n)
+                cb_bits = __hip_atomic_load(a.col_bound + cr.col_base + trow + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         {  // kept in scalar registers: the DMA instructions take a scalar base
             const uint64_t p = reinterpret_cast<uint64_t>(cr.z + trow * a.ld);
             const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p);
@@ -1006,6 +1081,18 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
     for (int ct = tile_begin; ct < tile_end; ++ct) {
         unsigned gb_bits = 0u;
         if (my_gb) gb_bits = __hip_atomic_load(my_gb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (COLSIDE) {
+            // the barrier that ended the previous tile also completed the loads of set_tile; the
+            // epilogue that reads cbound and appends to the queue is many barriers away
+            if (tid < BN) cbound[tid] = ordered_to_f32(cb_bits);
+            unsigned queued_cols = *lcnt;
+            if (queued_cols >= (unsigned)a.col_lds / 2) {  // uniform: drain the queue into the shows' buffers
+                if (queued_cols > (unsigned)a.col_lds) queued_cols = (unsigned)a.col_lds;
+                for (unsigned i = tid; i < queued_cols; i += TOPK_THREADS) col_append(a, lrowg[i], lkey[i]);
+                __syncthreads();
+                if (tid == 0) *lcnt = 0u;
+            }
+        }
 #pragma nounroll
         for (int kb = 0; kb < nkb; kb += 2) {
             dma_tile(kb + 1, tileC1);
@@ -1031,8 +1118,8 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
                     thr = fmaxf(thr, gbf);
                 }
             // ------------------------- epilogue (see cosine_tile_kernel) -------------------------
-            const ColRange& cr = a.rng[ct >= a.rng[0].tiles ? 1 : 0];
-            const int64_t trow = (int64_t)(ct >= a.rng[0].tiles ? ct - a.rng[0].tiles : ct) * BN;
+            const ColRange& cr = ct >= rng0.tiles ? rng1 : rng0;
+            const int64_t trow = (int64_t)(ct >= rng0.tiles ? ct - rng0.tiles : ct) * BN;
             const int64_t col0 = cr.col_base + trow;
             const int64_t col_end = cr.col_base + cr.n;
             const int64_t grow = a.q_row0 + q0 + lrow;
@@ -1117,6 +1204,59 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
                     }
                 }
             }
+            if (COLSIDE) {
+                // ---- column side: the same scores seen from the column shows.  Register r of
+                // sub-tile j belongs to column show 32 j + 8 (r >> 2) + 4 half + (r & 3), whose
+                // bound is the same for the 32 lanes of a half: four bounds per ds_read_b128.
+                if (q0 + BM > a.nq && q0 + lrow >= a.nq) {  // repeated rows past the end offer nothing
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[j][r] = -INFINITY;
+                }
+                const unsigned my_row = (unsigned)(a.q_row0 + q0 + lrow);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+                    for (int r0 = 0; r0 < 16; r0 += DMA_SLOTS) {
+                        const f32x4 cta = *reinterpret_cast<const f32x4*>(cbound + 32 * j + 2 * r0 + 4 * half);
+                        const f32x4 ctb = *reinterpret_cast<const f32x4*>(cbound + 32 * j + 2 * r0 + 8 + 4 * half);
+                        unsigned bits = 0u;
+                        int queued = 0;
+#pragma unroll
+                        for (int r = r0; r < r0 + DMA_SLOTS; ++r) {
+                            const float cthr = (r - r0) < 4 ? cta[r & 3] : ctb[r & 3];
+                            if (acc[j][r] >= cthr) {
+                                asm volatile("");  // keeps a real branch around the block
+                                scratch[queued * 64 + lane] = acc[j][r];
+                                ++queued;
+                                bits |= 1u << r;
+                            }
+                        }
+                        if (__any(bits != 0u)) {
+                            int slot = 0;
+                            while (__any(bits != 0u)) {
+                                const bool has = bits != 0u;
+                                const int r = has ? __builtin_ctz(bits) : 0;
+                                bits &= bits - 1u;
+                                const float v = scratch[slot * 64 + lane];
+                                ++slot;
+                                if (has) {
+                                    const unsigned rowg = (unsigned)col0 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * half;
+                                    const u64 key = make_key(v, (int)my_row);
+                                    const unsigned pos = atomicAdd(lcnt, 1u);
+                                    if (pos < (unsigned)a.col_lds) {
+                                        lkey[pos] = key;
+                                        lrowg[pos] = rowg;
+                                    } else {
+                                        col_append(a, rowg, key);  // queue full: straight to the show's buffer
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -1125,6 +1265,12 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
         }
+    }
+    if (COLSIDE) {  // what is still queued (the loop ended with a barrier)
+        __syncthreads();
+        unsigned queued_cols = *lcnt;
+        if (queued_cols > (unsigned)a.col_lds) queued_cols = (unsigned)a.col_lds;
+        for (unsigned i = tid; i < queued_cols; i += TOPK_THREADS) col_append(a, lrowg[i], lkey[i]);
     }
 
     // ---- final compaction and publication of this split's lists (per wave) ----
@@ -1161,15 +1307,23 @@ constexpr int FIN_MAX_KEYS = 2048;  // partial lists per row * k
 
 constexpr int FIN_ROWS = 2;  // rows (wavefronts) per workgroup
 
+// `gate` (may be null): when *gate != 0 the lists [alt_first, alt_first + alt_splits) are merged
+// instead of [0, splits) -- the symmetric sweep's complete re-run after a buffer overflow.
 __global__ __launch_bounds__(64 * FIN_ROWS) void topk_finalize_kernel(const u64* __restrict__ partial, int64_t nq,
                                                             int k, int splits, int32_t* __restrict__ out_idx,
                                                             float* __restrict__ out_score,
-                                                            int32_t* __restrict__ out_count) {
+                                                            int32_t* __restrict__ out_count,
+                                                            const unsigned* __restrict__ gate, int alt_first,
+                                                            int alt_splits) {
     __shared__ u64 buf[FIN_ROWS][FIN_MAX_KEYS];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int64_t row = (int64_t)blockIdx.x * FIN_ROWS + wave;
     if (row >= nq) return;
+    if (gate && *gate != 0u) {
+        partial += (int64_t)alt_first * nq * k;
+        splits = alt_splits;
+    }
     u64* b = buf[wave];
     const int m = splits * k;
     // gather the non-empty keys of all partial lists, packed (most slots of late splits are empty
@@ -1208,6 +1362,56 @@ __global__ __launch_bounds__(64 * FIN_ROWS) void topk_finalize_kernel(const u64*
         out_score[row * k + i] = 0.f;
     }
     if (lane == 0) out_count[row] = cnt;
+}
+
+// --------------------------------------------------------------------------
+// Column-side buffers -> one more partial list per show.  One wavefront per show: entries that
+// reach the show's final bound are packed into LDS, ranked by counting, and the K best written
+// in the partial-list format (descending, empty slots = sentinel).
+// --------------------------------------------------------------------------
+constexpr int COL_CAP_MAX = 1024;
+constexpr int COLRED_ROWS = 4;
+
+__global__ __launch_bounds__(64 * COLRED_ROWS) void col_reduce_kernel(const unsigned* __restrict__ col_cnt,
+                                                                      const u64* __restrict__ col_buf, int col_cap,
+                                                                      const unsigned* __restrict__ bound, int64_t n,
+                                                                      int k, float min_similarity,
+                                                                      u64* __restrict__ out) {
+    __shared__ u64 buf[COLRED_ROWS][COL_CAP_MAX];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * COLRED_ROWS + wave;
+    if (row >= n) return;
+    u64* b = buf[wave];
+    int m = (int)col_cnt[row];
+    if (m > col_cap) m = col_cap;
+    const unsigned thr = bound[row];
+    const u64* src = col_buf + row * col_cap;
+    int packed = 0;
+    for (int i0 = 0; i0 < m; i0 += 64) {
+        const int i = i0 + lane;
+        const u64 key = i < m ? src[i] : 0ull;
+        const bool keep = i < m && (unsigned)(key >> 32) >= thr;
+        const u64 mask = __ballot(keep);
+        if (keep) b[packed + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = key;
+        packed += __builtin_popcountll(mask);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    u64* dst = out + row * k;
+    for (int i = lane; i < packed; i += 64) {
+        const u64 me = b[i];
+        int rank = 0;
+        for (int j = 0; j < packed; ++j) rank += (b[j] > me) ? 1 : 0;
+        if (rank < k) dst[rank] = me;
+    }
+    const u64 empty = sentinel_key(min_similarity);
+    for (int i = (packed < k ? packed : k) + lane; i < k; i += 64) dst[i] = empty;
+}
+
+__global__ __launch_bounds__(256) void fill_u32_kernel(unsigned* __restrict__ p, int64_t count, unsigned v) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) p[i] = v;
 }
 
 // --------------------------------------------------------------------------
@@ -1749,7 +1953,7 @@ int tvbf_topk_finish(int64_t nq, int k, int slots, int32_t* out_idx, float* out_
     hipLaunchKernelGGL(topk_finalize_kernel, dim3((unsigned)((nq + FIN_ROWS - 1) / FIN_ROWS)), dim3(64 * FIN_ROWS), 0,
                        (hipStream_t)stream,
                        reinterpret_cast<const u64*>(ws + ws_bound_bytes(nq)), nq, k, slots, out_idx, out_score,
-                       out_count);
+                       out_count, (const unsigned*)nullptr, 0, 0);
     HIP_TRY(hipGetLastError());
     return TVBF_OK;
 }
@@ -1773,6 +1977,157 @@ int tvbf_cosine_topk_f32(const float* Zq, int64_t nq, int64_t q_row0, const floa
                                   workspace, workspace_bytes, 0, max_merge_slots(k), &used, stream);
     if (rc) return rc;
     return tvbf_topk_finish(nq, k, used, out_idx, out_score, out_count, workspace, workspace_bytes, stream);
+}
+
+// ---- symmetric whole-catalogue sweep ----
+// Z Z^T is symmetric bit for bit, so every pair of different shows needs computing only once.
+// The row blocks are grouped into `shards`:
+//   1. every shard against its own columns (row side only) -- 1 / shards of the work, and every
+//      show gets a bound on its K-th score from a sizeable sample of the catalogue;
+//   2. every shard against the half of the other shards that follows it cyclically, both sides:
+//      the row side feeds the lists as usual, the column side appends the scores that reach the
+//      bound of their column's show to that show's buffer (first into an LDS queue, drained with
+//      one global atomic per entry);
+//   3. the buffers are reduced to one more partial list per show, and the usual merge follows.
+// A show's buffer holds col_cap entries; should one overflow (hundreds of exact ties at a
+// show's K-th score can do that), a flag makes a plain sweep -- launched in any case, but
+// returning at once while the flag is clear -- recompute everything, and the merge takes its
+// lists instead.  No host synchronisation anywhere.
+struct SymPlan {
+    bool ok;
+    int row_blocks, sh_blocks, shards;
+    int s_diag, s_half, s_full;  // column splits (= list slots) of the three sweeps
+    int col_cap, col_lds;
+    size_t lds_diag, lds_half;
+    size_t off_cnt, off_flag, off_buf, bytes;
+};
+
+static SymPlan make_sym_plan(int64_t n, int64_t d, int k) {
+    SymPlan sp;
+    memset(&sp, 0, sizeof(sp));
+    if (n < 1 || k < 1 || k > TVBF_MAX_K || !topk_use_dma(d) || topk_list_global(k)) return sp;
+    sp.row_blocks = (int)((n + BM - 1) / BM);
+    int target = 16;
+    if (const char* e = getenv("TVBF_SYM_SHARDS")) target = atoi(e);
+    if (target < 2) target = 2;
+    sp.sh_blocks = (sp.row_blocks + target - 1) / target;
+    sp.shards = (sp.row_blocks + sp.sh_blocks - 1) / sp.sh_blocks;
+    if (sp.shards < 2) return sp;
+    const int cus = device_cus();
+    const int slots = max_merge_slots(k);
+    sp.s_diag = make_plan(n, sp.sh_blocks, d, k, cus, slots).splits;
+    sp.s_half = make_plan(n, (sp.shards - 1) * sp.sh_blocks / 2 + 1, d, k, cus, slots).splits;
+    const Plan full = make_plan(n, tiles_of(n), d, k, cus, slots);
+    sp.s_full = full.splits;
+    if (sp.s_diag + sp.s_half + 1 > slots || sp.s_full > slots) return sp;
+    sp.lds_diag = full.lds_bytes;
+    // the column queue takes what is left of half a CU's LDS beside the lists and the tiles
+    const size_t fixed = full.lds_bytes + topk_static_lds_bytes(d) + BN * sizeof(float) + 16;
+    const size_t room = fixed < 80 * 1024 ? 80 * 1024 - fixed : 0;
+    sp.col_lds = (int)(room / 12) / 64 * 64;
+    if (sp.col_lds > 1024) sp.col_lds = 1024;
+    if (sp.col_lds < 128) return sp;
+    sp.lds_half = full.lds_bytes + BN * sizeof(float) + 16 + (size_t)sp.col_lds * 12;
+    sp.col_cap = 512;
+    if (const char* e = getenv("TVBF_SYM_COL_CAP")) sp.col_cap = atoi(e);  // tuning / test aid
+    if (sp.col_cap < 1) sp.col_cap = 1;
+    if (sp.col_cap > COL_CAP_MAX) sp.col_cap = COL_CAP_MAX;
+    const int lists = sp.s_diag + sp.s_half + 1 + sp.s_full;
+    sp.off_cnt = ws_bound_bytes(n) + (size_t)lists * ws_slot_bytes(n, k);
+    sp.off_flag = sp.off_cnt + ws_bound_bytes(n);
+    sp.off_buf = sp.off_flag + 16;
+    sp.bytes = sp.off_buf + (size_t)n * sp.col_cap * 8;
+    sp.ok = true;
+    return sp;
+}
+
+size_t tvbf_cosine_topk_sym_workspace_bytes(int64_t n, int64_t d, int k) {
+    const SymPlan sp = make_sym_plan(n, d, k);
+    return sp.ok ? sp.bytes : 0;
+}
+
+int tvbf_cosine_topk_sym_f32(const float* Z, int64_t n, int64_t d, int64_t ld, int k, float min_similarity,
+                             int exclude_self, int32_t* out_idx, float* out_score, int32_t* out_count,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+    if (!Z || !out_idx || !out_score || !out_count) return fail(TVBF_E_BAD_ARG, "null pointer argument");
+    if (n < 1) return fail(TVBF_E_BAD_ARG, "bad n");
+    int rc = validate_accumulate(Z, n, 0, d, ld, Z, n, 0, nullptr, 0, 0, k, min_similarity, workspace, 0,
+                                 max_merge_slots(k));
+    if (rc) return rc;
+    const SymPlan sp = make_sym_plan(n, d, k);
+    if (!sp.ok)
+        return fail(TVBF_E_BAD_SHAPE, "the symmetric sweep needs d %% 64 == 0, k <= 24 and at least two shards of rows");
+    if (workspace_bytes < sp.bytes) return fail(TVBF_E_BAD_SHAPE, "workspace must be >= %zu bytes", sp.bytes);
+    if (min_similarity < -FLT_MAX) min_similarity = -FLT_MAX;
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = reinterpret_cast<char*>(workspace);
+    unsigned* bound = reinterpret_cast<unsigned*>(ws);
+    unsigned* col_cnt = reinterpret_cast<unsigned*>(ws + sp.off_cnt);
+    unsigned* flag = reinterpret_cast<unsigned*>(ws + sp.off_flag);
+    u64* col_buf = reinterpret_cast<u64*>(ws + sp.off_buf);
+    u64* lists = reinterpret_cast<u64*>(ws + ws_bound_bytes(n));
+    const size_t slot_keys = (size_t)n * k;
+
+    hipLaunchKernelGGL(bound_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, bound, n,
+                       f32_to_ordered(min_similarity));
+    // counters and the flag behind them are one stretch of the workspace
+    const int64_t words = (int64_t)((sp.off_buf - sp.off_cnt) / 4);
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, col_cnt, words, 0u);
+
+    TopkArgs a;
+    memset(&a, 0, sizeof(a));
+    a.zq = Z;
+    a.rng[0] = ColRange{Z, n, 0, tiles_of(n)};
+    a.rng[1] = ColRange{Z, 0, 0, 0};
+    a.bound = bound;
+    a.nq = n;
+    a.q_row0 = 0;
+    a.ld = ld;
+    a.d = (int)d;
+    a.k = k;
+    a.cap = topk_cap(k, d);
+    a.row_blocks = sp.row_blocks;
+    a.col_tiles = tiles_of(n);
+    a.min_similarity = min_similarity;
+    a.exclude_self = exclude_self;
+    a.sh_blocks = sp.sh_blocks;
+    a.shards = sp.shards;
+    a.col_bound = bound;
+    a.col_cnt = col_cnt;
+    a.col_buf = col_buf;
+    a.col_cap = sp.col_cap;
+    a.col_lds = sp.col_lds;
+    a.overflow = flag;
+
+    const void* k_diag = reinterpret_cast<const void*>(cosine_topk_dma_kernel<false, SYM_DIAG>);
+    const void* k_half = reinterpret_cast<const void*>(cosine_topk_dma_kernel<false, SYM_HALF>);
+    const void* k_full = reinterpret_cast<const void*>(cosine_topk_dma_kernel<false, SYM_OFF>);
+    HIP_TRY(hipFuncSetAttribute(k_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.lds_diag));
+    HIP_TRY(hipFuncSetAttribute(k_half, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.lds_half));
+    HIP_TRY(hipFuncSetAttribute(k_full, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.lds_diag));
+
+    a.partial = lists;
+    a.splits = sp.s_diag;
+    hipLaunchKernelGGL((cosine_topk_dma_kernel<false, SYM_DIAG>), dim3((unsigned)(sp.row_blocks * sp.s_diag)),
+                       dim3(TOPK_THREADS), sp.lds_diag, st, a);
+    a.partial = lists + (size_t)sp.s_diag * slot_keys;
+    a.splits = sp.s_half;
+    hipLaunchKernelGGL((cosine_topk_dma_kernel<false, SYM_HALF>), dim3((unsigned)(sp.row_blocks * sp.s_half)),
+                       dim3(TOPK_THREADS), sp.lds_half, st, a);
+    hipLaunchKernelGGL(col_reduce_kernel, dim3((unsigned)((n + COLRED_ROWS - 1) / COLRED_ROWS)), dim3(64 * COLRED_ROWS),
+                       0, st, col_cnt, col_buf, sp.col_cap, bound, n, k, min_similarity,
+                       lists + (size_t)(sp.s_diag + sp.s_half) * slot_keys);
+    // the complete plain sweep: a no-op unless a buffer overflowed
+    const int first_full = sp.s_diag + sp.s_half + 1;
+    a.partial = lists + (size_t)first_full * slot_keys;
+    a.splits = sp.s_full;
+    a.gate = flag;
+    hipLaunchKernelGGL((cosine_topk_dma_kernel<false, SYM_OFF>), dim3((unsigned)(sp.row_blocks * sp.s_full)),
+                       dim3(TOPK_THREADS), sp.lds_diag, st, a);
+    hipLaunchKernelGGL(topk_finalize_kernel, dim3((unsigned)((n + FIN_ROWS - 1) / FIN_ROWS)), dim3(64 * FIN_ROWS), 0, st,
+                       lists, n, k, first_full, out_idx, out_score, out_count, flag, first_full, sp.s_full);
+    HIP_TRY(hipGetLastError());
+    return TVBF_OK;
 }
 
 // Partial lists per query: every selection wave should see a few thousand scores.

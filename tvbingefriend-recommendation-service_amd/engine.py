@@ -202,6 +202,44 @@ def cosine_topk(z_all: torch.Tensor, k: int, min_similarity: float, *, q_row0: i
     return out
 
 
+def symmetric_workspace_bytes(n: int, ld: int, k: int) -> int:
+    """Workspace of :func:`cosine_topk_symmetric`; 0 when that route does not take the shape
+    (row length not a multiple of 64, k above 24, fewer than two shards of rows)."""
+    return int(native.load().tvbf_cosine_topk_sym_workspace_bytes(int(n), int(ld), int(k)))
+
+
+def cosine_topk_symmetric(z: torch.Tensor, k: int, min_similarity: float, *, n: int | None = None,
+                          exclude_self: bool = True, workspace: torch.Tensor | None = None,
+                          out: TopK | None = None) -> TopK:
+    """Top-k of every row of ``z[:n] @ z[:n].T`` computing each pair of shows once: the score
+    matrix is symmetric bit for bit, so the lists equal :func:`cosine_topk`'s exactly."""
+    _require_cuda(z, "z")
+    if z.dim() != 2 or not z.is_contiguous():
+        raise ValueError("z must be a contiguous 2-D tensor")
+    n = z.shape[0] if n is None else int(n)
+    if not 1 <= n <= z.shape[0]:
+        raise ValueError("n outside z")
+    ld = z.shape[1]
+    dev = z.device
+    lib = native.load()
+    with torch.cuda.device(dev):
+        need = int(lib.tvbf_cosine_topk_sym_workspace_bytes(n, ld, k))
+        if need == 0:
+            raise ValueError("the symmetric route does not take this shape (see symmetric_workspace_bytes)")
+        if workspace is None:
+            workspace = torch.empty((need + 15) // 16 * 2, dtype=torch.int64, device=dev)
+        if out is None:
+            out = TopK(torch.empty((n, k), dtype=torch.int32, device=dev),
+                       torch.empty((n, k), dtype=torch.float32, device=dev),
+                       torch.empty((n,), dtype=torch.int32, device=dev))
+        rc = lib.tvbf_cosine_topk_sym_f32(z.data_ptr(), n, ld, ld, k, float(min_similarity),
+                                          1 if exclude_self else 0, out.idx.data_ptr(), out.score.data_ptr(),
+                                          out.count.data_ptr(), workspace.data_ptr(),
+                                          workspace.numel() * workspace.element_size(), _stream_ptr())
+    native.check(rc, "tvbf_cosine_topk_sym_f32")
+    return out
+
+
 def component_scores(z_all: torch.Tensor, offsets, scales, idx: torch.Tensor, *, q_row0: int = 0,
                      n: int | None = None, z_q: torch.Tensor | None = None) -> torch.Tensor:
     """Per-block cosines (nq, k, nb) of the kept pairs listed in ``idx``."""

@@ -80,7 +80,7 @@ def column_pieces(shard: Shard):
 
 
 def sharded_topk(x_shard: torch.Tensor, offsets, scales, shard: Shard, k: int, min_similarity: float,
-                 group=None, normalize_fn=None, session_fn=None):
+                 group=None, normalize_fn=None, session_fn=None, collective=None):
     """normalise own rows -> all-gather (asynchronous) -> top-K of own rows against all n columns.
 
     The rank first scores its rows against its own shard, which overlaps the collective, then
@@ -88,6 +88,8 @@ def sharded_topk(x_shard: torch.Tensor, offsets, scales, shard: Shard, k: int, m
     rank's rows padded to (per_rank, d).  ``normalize_fn(x, offsets, scales)`` and
     ``session_fn(z_q, nq, q_row0, k, min_similarity)`` default to the HIP kernels
     (engine.normalize_blocks / engine.TopkSession); tests of the host logic inject CPU stand-ins.
+    ``collective`` (default: world > 1) forces the all-gather route also for a one-rank group,
+    which is how the RCCL route is exercised on a single GPU.
     Returns (TopK of the rank's ``shard.rows`` rows, z_all).
     """
     if normalize_fn is None or session_fn is None:
@@ -98,7 +100,11 @@ def sharded_topk(x_shard: torch.Tensor, offsets, scales, shard: Shard, k: int, m
     if x_shard.shape[0] != shard.per_rank:
         raise ValueError("x_shard must be padded to per_rank rows")
     z_shard = normalize_fn(x_shard, offsets, scales)
-    if shard.world == 1:
+    if collective is None:
+        collective = shard.world > 1
+    if not collective:
+        if shard.world != 1:
+            raise ValueError("a sharded job needs the collective")
         session = session_fn(z_shard, shard.rows, 0, k, min_similarity)
         session.accumulate((z_shard, shard.rows, 0))
         return session.finish(), z_shard
