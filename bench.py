@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo is a rehearsal mode: the shards are exchanged through host memory")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline sample")
+    ap.add_argument("--sweep", choices=["auto", "plain", "symmetric"], default="auto",
+                    help="single GPU: 'symmetric' computes every pair of shows once (identical lists); "
+                         "auto takes it whenever the library accepts the shape")
     return ap.parse_args()
 
 
@@ -179,6 +182,12 @@ def main():
     slots = 16 if world == 1 else 32
     ws_bytes = int(native.load().tvbf_topk_workspace_bytes_for_slots(max(nq, 1), args.k, slots))
     workspace = torch.empty((ws_bytes + 15) // 16 * 2, dtype=torch.int64, device=dev)
+    sym_bytes = engine.symmetric_workspace_bytes(nq, ld, args.k) if world == 1 and args.sweep != "plain" else 0
+    if args.sweep == "symmetric" and not sym_bytes:
+        raise SystemExit("--sweep symmetric: one GPU, row length a multiple of 64 and k <= 24 only")
+    symmetric = sym_bytes > 0
+    if symmetric:
+        workspace = torch.empty((sym_bytes + 15) // 16 * 2, dtype=torch.int64, device=dev)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     kernel_ms = []
     own, after, before = sharding.column_pieces(shard)
@@ -205,14 +214,19 @@ def main():
     def step(timed):
         engine.normalize_blocks(x, offsets, scales, out=z_shard)
         work = start_gather()
-        session = engine.TopkSession(z_shard, nq, shard.row0, args.k, min_sim, slots=slots, workspace=workspace)
-        if timed:
-            ev[0].record()
-        session.accumulate((z_shard, own[1], own[0]))  # own columns: overlaps the all-gather
-        if work is not None:
-            work.wait()
-            session.accumulate((z_all[after[0]:], after[1], after[0]), (z_all, before[1], before[0]))
-        session.finish(out)
+        if symmetric:
+            if timed:
+                ev[0].record()
+            engine.cosine_topk_symmetric(z_shard, args.k, min_sim, n=nq, workspace=workspace, out=out)
+        else:
+            session = engine.TopkSession(z_shard, nq, shard.row0, args.k, min_sim, slots=slots, workspace=workspace)
+            if timed:
+                ev[0].record()
+            session.accumulate((z_shard, own[1], own[0]))  # own columns: overlaps the all-gather
+            if work is not None:
+                work.wait()
+                session.accumulate((z_all[after[0]:], after[1], after[0]), (z_all, before[1], before[0]))
+            session.finish(out)
         if timed:
             ev[1].record()
         comp = engine.component_scores(z_all, offsets, scales, out.idx, q_row0=shard.row0, n=args.n)
@@ -256,7 +270,8 @@ def main():
     tf = ROOT / "profiles" / "traffic.json"
     if tf.exists():
         try:
-            traffic = json.loads(tf.read_text()).get(f"n{args.n}_d{args.d}_k{args.k}_{args.data}_g{world}")
+            key = f"n{args.n}_d{args.d}_k{args.k}_{args.data}_g{world}" + ("_sym" if symmetric else "")
+            traffic = json.loads(tf.read_text()).get(key)
         except Exception:
             traffic = None
     line = {
@@ -273,12 +288,17 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": workload, "rows_per_gpu": per_rank_rows,
-                   "parallelism": f"row-shard x{world} + all-gather ({args.backend})" if world > 1 else "single GPU"},
+                   "parallelism": f"row-shard x{world} + all-gather ({args.backend})" if world > 1 else "single GPU",
+                   "sweep": "symmetric: every unordered pair of shows computed once, both shows' lists fed from it; "
+                            "flops counted as 2*N^2*D all the same" if symmetric else "plain: every ordered pair computed"},
         "topk_build_time_s": elapsed / args.steps,
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                     "kernel": "cosine_topk_dma_kernel<false> (HIP events also span the 4 us bound fill and the "
-                               "0.3 ms list merge of the same call)", "kernel_ms": kernel_avg_ms},
+                     "kernel": ("cosine_topk_dma_kernel<false, 1> + <false, 2> (own-shard and half sweeps of the symmetric "
+                                "route; HIP events span the whole call: fills, column-buffer reduction, list merge)"
+                                if symmetric else
+                                "cosine_topk_dma_kernel<false, 0> (HIP events also span the 4 us bound fill and the "
+                                "0.3 ms list merge of the same call)"), "kernel_ms": kernel_avg_ms},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         x_host = x[:nq].cpu().numpy()

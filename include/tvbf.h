@@ -157,7 +157,7 @@ int tvbf_cosine_topk_f32(const float* Zq, int64_t nq, int64_t q_row0, const floa
  *               n large enough for two shards of 128-row blocks
  *   workspace   >= tvbf_cosine_topk_sym_workspace_bytes(n, d, k) bytes, which returns 0 when
  *               the shape is not taken (call tvbf_cosine_topk_f32 then)
- * Every show has a buffer of 512 column-side candidates; should one overflow (hundreds of exact
+ * Every show has a buffer of 1024 column-side candidates; should one overflow (a thousand exact
  * ties at a show's K-th score), the call recomputes the plain way on the device, without host
  * synchronisation -- correct, at the plain sweep's cost on top.
  */
@@ -165,6 +165,14 @@ size_t tvbf_cosine_topk_sym_workspace_bytes(int64_t n, int64_t d, int k);
 int tvbf_cosine_topk_sym_f32(const float* Z, int64_t n, int64_t d, int64_t ld, int k, float min_similarity,
                              int exclude_self, int32_t* out_idx, float* out_score, int32_t* out_count,
                              void* workspace, size_t workspace_bytes, void* stream);
+/*
+ * Diagnostics of the last tvbf_cosine_topk_sym_f32 call on `workspace` (synchronises the stream;
+ * no counterpart in the reference): out4 = { 1 if a column buffer overflowed and the plain sweep
+ * recomputed the lists, column-side candidates appended in total, the largest number appended
+ * for one show, that show's row }.
+ */
+int tvbf_cosine_topk_sym_inspect(const void* workspace, int64_t n, int64_t d, int k, int64_t* out4,
+                                 void* stream);
 
 /*
  * Incremental form of tvbf_cosine_topk_f32 for callers that receive the columns

@@ -331,6 +331,7 @@ def test_rccl_route_one_rank_group(pkg, device):
     import torch
     import torch.distributed as dist
 
+    from synth import hybrid_like_blocks
     from tvbingefriend_recommendation_service_amd import engine, sharding
 
     n, k, ms = 3000, 20, 0.1

@@ -30,6 +30,24 @@ def _z_hybrid(device, n, seed, d_genre=16, d_text=208):
     return engine.normalize_blocks(torch.from_numpy(x).to(device), offsets, scales), x, offsets
 
 
+def _sym(z, k, ms, expect_overflow=False, **kw):
+    """Symmetric sweep on its own workspace; checks whether the lists came from the symmetric
+    route itself or from the plain re-run after an overflow."""
+    import torch
+
+    from tvbingefriend_recommendation_service_amd import engine
+
+    n, ld = z.shape
+    nbytes = engine.symmetric_workspace_bytes(n, ld, k)
+    assert nbytes > 0
+    ws = torch.empty((nbytes + 15) // 16 * 2, dtype=torch.int64, device=z.device)
+    top = engine.cosine_topk_symmetric(z, k, ms, workspace=ws, **kw)
+    info = engine.symmetric_inspect(ws, n, ld, k)
+    assert info["overflowed"] == expect_overflow, info
+    assert info["appended"] > 0
+    return top
+
+
 def _assert_same(a, b, what):
     assert np.array_equal(_to_np(a.count), _to_np(b.count)), what
     assert np.array_equal(_to_np(a.idx), _to_np(b.idx)), what
@@ -48,7 +66,7 @@ def test_symmetric_equals_plain_hybrid(pkg, device, monkeypatch, n, shards):
     assert z.shape[1] % 64 == 0
     for k, ms in ((20, 0.1), (7, 0.3)):
         plain = engine.cosine_topk(z, k, ms)
-        sym = engine.cosine_topk_symmetric(z, k, ms)
+        sym = _sym(z, k, ms)
         torch.cuda.synchronize()
         _assert_same(sym, plain, f"n={n} shards={shards} k={k}")
 
@@ -62,7 +80,7 @@ def test_symmetric_dense_against_oracle(pkg, device, n, d, k):
 
     x = dense_gaussian(n, d, seed=77 + n)
     z = engine.normalize_blocks(torch.from_numpy(x).to(device), [0, d], [1.0])
-    sym = engine.cosine_topk_symmetric(z, k, -1.0)
+    sym = _sym(z, k, -1.0)
     plain = engine.cosine_topk(z, k, -1.0)
     torch.cuda.synchronize()
     _assert_same(sym, plain, f"dense {n}x{d}")
@@ -77,7 +95,7 @@ def test_symmetric_keeps_self_when_asked(pkg, device):
     from tvbingefriend_recommendation_service_amd import engine
 
     z, _, _ = _z_hybrid(device, 1800, seed=9)
-    sym = engine.cosine_topk_symmetric(z, 10, 0.1, exclude_self=False)
+    sym = _sym(z, 10, 0.1, exclude_self=False)
     plain = engine.cosine_topk(z, 10, 0.1, exclude_self=False)
     torch.cuda.synchronize()
     _assert_same(sym, plain, "exclude_self=False")
@@ -95,7 +113,7 @@ def test_symmetric_overflow_recomputes_plainly(pkg, device, monkeypatch):
     z, _, _ = _z_hybrid(device, 1700, seed=31)
     plain = engine.cosine_topk(z, 20, 0.1)
     monkeypatch.setenv("TVBF_SYM_COL_CAP", "2")
-    sym = engine.cosine_topk_symmetric(z, 20, 0.1)
+    sym = _sym(z, 20, 0.1, expect_overflow=True)
     torch.cuda.synchronize()
     _assert_same(sym, plain, "overflow")
 
@@ -112,7 +130,7 @@ def test_symmetric_with_cliques_of_identical_shows(pkg, device):
     x = base[rng.integers(0, 60, size=2500)]  # about 40 copies of each of 60 shows
     z = engine.normalize_blocks(torch.from_numpy(np.ascontiguousarray(x)).to(device), [0, 128], [1.0])
     for k in (5, 20):
-        sym = engine.cosine_topk_symmetric(z, k, -1.0)
+        sym = _sym(z, k, -1.0)
         plain = engine.cosine_topk(z, k, -1.0)
         torch.cuda.synchronize()
         _assert_same(sym, plain, f"cliques k={k}")
@@ -150,7 +168,7 @@ def test_symmetric_benchmark_shape_sample(pkg, device):
     x[torch.arange(n, device=device), d - 32 + torch.randint(0, 32, (n,), generator=gen, device=device)] = 1.0
     z = engine.normalize_blocks(x, [0, 32, d - 32, d], [float(np.sqrt(w)) for w in (0.4, 0.5, 0.1)])
     del x
-    sym = engine.cosine_topk_symmetric(z, k, ms)
+    sym = _sym(z, k, ms)
     plain = engine.cosine_topk(z, k, ms)
     torch.cuda.synchronize()
     assert torch.equal(sym.count, plain.count)

@@ -34,7 +34,9 @@ z = engine.normalize_blocks(x, offsets, scales)
 del x
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 res = {}
-for name, fn in (("plain", lambda: engine.cosine_topk(z, k, ms)), ("symmetric", lambda: engine.cosine_topk_symmetric(z, k, ms))):
+nbytes = engine.symmetric_workspace_bytes(n, z.shape[1], k)
+ws = torch.empty((nbytes + 15) // 16 * 2, dtype=torch.int64, device=dev)
+for name, fn in (("plain", lambda: engine.cosine_topk(z, k, ms)), ("symmetric", lambda: engine.cosine_topk_symmetric(z, k, ms, workspace=ws))):
     ts = []
     for _ in range(iters + 1):
         ev[0].record(); out = fn(); ev[1].record(); torch.cuda.synchronize()
@@ -43,4 +45,4 @@ for name, fn in (("plain", lambda: engine.cosine_topk(z, k, ms)), ("symmetric", 
     best = min(ts[1:])
     print(f"{name:10s} {best:8.2f} ms  (runs: {' '.join('%.1f' % v for v in ts)})  {2.0 * n * n * d / best / 1e9:.1f} TFLOP/s of 2 N^2 D", flush=True)
 same = all(torch.equal(getattr(res["plain"], f), getattr(res["symmetric"], f)) for f in ("idx", "score", "count"))
-print("identical lists:", same)
+print("identical lists:", same, engine.symmetric_inspect(ws, n, z.shape[1], k))

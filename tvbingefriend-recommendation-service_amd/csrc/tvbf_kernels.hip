@@ -8,6 +8,7 @@
 // The C ABI is declared in include/tvbf.h.  No torch types, no allocation.
 
 #include <hip/hip_runtime.h>
+#include <vector>
 #include <stdint.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -169,8 +170,8 @@ struct TopkArgs {
     const unsigned* st_prefix;  // [2] key prefixes selected by the earlier levels
     int st_level, st_chunk;     // radix level 0..2; column tiles per workgroup
     // symmetric sweep (query rows and columns are the same matrix, given whole as rng[0]): the row
-    // blocks form `shards` groups of sh_blocks; the kernel derives each group's column ranges
-    int sh_blocks, shards;
+    // blocks form `shards` groups of (nearly) equal size; the kernel derives each group's column ranges
+    int shards;
     // column side of a tile: a score that reaches the bound of its COLUMN's show is appended to
     // that show's buffer -- the pair is then never computed with the roles swapped
     const unsigned* col_bound;  // [shows] lower bounds of the K-th scores (ordered bits), by global row
@@ -914,16 +915,18 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
     ColRange rng0 = a.rng[0], rng1 = a.rng[1];
     int col_tiles = a.col_tiles;
     if (SYM != SYM_OFF) {
-        const int64_t shard_rows = (int64_t)a.sh_blocks * BM, n_all = a.rng[0].n;
+        // shard s = row blocks [s * row_blocks / shards, (s + 1) * row_blocks / shards): sizes differ by one block at most
+        const int64_t n_all = a.rng[0].n;
         const float* z_all = a.rng[0].z;
         const int64_t ld = a.ld;
+        const int RB = a.row_blocks, V = a.shards;
         auto span = [=](int first, int count) {  // shards [first, first + count), count >= 0, no wrap
-            const int64_t r0 = first * shard_rows;
-            int64_t r1 = (first + count) * shard_rows;
+            const int64_t r0 = (int64_t)(((int64_t)first * RB) / V) * BM;
+            int64_t r1 = (int64_t)(((int64_t)(first + count) * RB) / V) * BM;
             if (r1 > n_all) r1 = n_all;
             return ColRange{z_all + r0 * ld, r1 - r0, r0, (int)((r1 - r0 + BN - 1) / BN)};
         };
-        const int v = rb / a.sh_blocks, V = a.shards;
+        const int v = (int)((((int64_t)rb + 1) * V - 1) / RB);
         if (SYM == SYM_DIAG) {
             rng0 = span(v, 1);
             rng1 = span(0, 0);
@@ -1995,7 +1998,7 @@ int tvbf_cosine_topk_f32(const float* Zq, int64_t nq, int64_t q_row0, const floa
 // lists instead.  No host synchronisation anywhere.
 struct SymPlan {
     bool ok;
-    int row_blocks, sh_blocks, shards;
+    int row_blocks, shards;
     int s_diag, s_half, s_full;  // column splits (= list slots) of the three sweeps
     int col_cap, col_lds;
     size_t lds_diag, lds_half;
@@ -2007,16 +2010,18 @@ static SymPlan make_sym_plan(int64_t n, int64_t d, int k) {
     memset(&sp, 0, sizeof(sp));
     if (n < 1 || k < 1 || k > TVBF_MAX_K || !topk_use_dma(d) || topk_list_global(k)) return sp;
     sp.row_blocks = (int)((n + BM - 1) / BM);
-    int target = 16;
-    if (const char* e = getenv("TVBF_SYM_SHARDS")) target = atoi(e);
+    // shards: few enough that the own-columns sweep gives every show a bound from >= 1024
+    // columns, many enough that this sweep (1 / shards of all pairs, computed twice) stays small
+    int target = sp.row_blocks / 8 < 48 ? sp.row_blocks / 8 : 48;
+    if (const char* e = getenv("TVBF_SYM_SHARDS")) target = atoi(e);  // tuning / test aid
     if (target < 2) target = 2;
-    sp.sh_blocks = (sp.row_blocks + target - 1) / target;
-    sp.shards = (sp.row_blocks + sp.sh_blocks - 1) / sp.sh_blocks;
+    sp.shards = target < sp.row_blocks ? target : sp.row_blocks;
     if (sp.shards < 2) return sp;
+    const int sh_blocks = (sp.row_blocks + sp.shards - 1) / sp.shards;  // the larger shards
     const int cus = device_cus();
     const int slots = max_merge_slots(k);
-    sp.s_diag = make_plan(n, sp.sh_blocks, d, k, cus, slots).splits;
-    sp.s_half = make_plan(n, (sp.shards - 1) * sp.sh_blocks / 2 + 1, d, k, cus, slots).splits;
+    sp.s_diag = make_plan(n, sh_blocks, d, k, cus, slots).splits;
+    sp.s_half = make_plan(n, (sp.shards - 1) * sh_blocks / 2 + 1, d, k, cus, slots).splits;
     const Plan full = make_plan(n, tiles_of(n), d, k, cus, slots);
     sp.s_full = full.splits;
     if (sp.s_diag + sp.s_half + 1 > slots || sp.s_full > slots) return sp;
@@ -2028,7 +2033,7 @@ static SymPlan make_sym_plan(int64_t n, int64_t d, int k) {
     if (sp.col_lds > 1024) sp.col_lds = 1024;
     if (sp.col_lds < 128) return sp;
     sp.lds_half = full.lds_bytes + BN * sizeof(float) + 16 + (size_t)sp.col_lds * 12;
-    sp.col_cap = 512;
+    sp.col_cap = 1024;
     if (const char* e = getenv("TVBF_SYM_COL_CAP")) sp.col_cap = atoi(e);  // tuning / test aid
     if (sp.col_cap < 1) sp.col_cap = 1;
     if (sp.col_cap > COL_CAP_MAX) sp.col_cap = COL_CAP_MAX;
@@ -2090,7 +2095,6 @@ int tvbf_cosine_topk_sym_f32(const float* Z, int64_t n, int64_t d, int64_t ld, i
     a.col_tiles = tiles_of(n);
     a.min_similarity = min_similarity;
     a.exclude_self = exclude_self;
-    a.sh_blocks = sp.sh_blocks;
     a.shards = sp.shards;
     a.col_bound = bound;
     a.col_cnt = col_cnt;
@@ -2127,6 +2131,26 @@ int tvbf_cosine_topk_sym_f32(const float* Z, int64_t n, int64_t d, int64_t ld, i
     hipLaunchKernelGGL(topk_finalize_kernel, dim3((unsigned)((n + FIN_ROWS - 1) / FIN_ROWS)), dim3(64 * FIN_ROWS), 0, st,
                        lists, n, k, first_full, out_idx, out_score, out_count, flag, first_full, sp.s_full);
     HIP_TRY(hipGetLastError());
+    return TVBF_OK;
+}
+
+int tvbf_cosine_topk_sym_inspect(const void* workspace, int64_t n, int64_t d, int k, int64_t* out4, void* stream) {
+    if (!workspace || !out4) return fail(TVBF_E_BAD_ARG, "null pointer argument");
+    const SymPlan sp = make_sym_plan(n, d, k);
+    if (!sp.ok) return fail(TVBF_E_BAD_SHAPE, "not a shape of the symmetric sweep");
+    std::vector<unsigned> host((sp.off_buf - sp.off_cnt) / 4);
+    HIP_TRY(hipMemcpyAsync(host.data(), reinterpret_cast<const char*>(workspace) + sp.off_cnt, host.size() * 4,
+                           hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    int64_t total = 0, worst = 0, worst_row = -1;
+    for (int64_t i = 0; i < n; ++i) {
+        total += host[i];
+        if ((int64_t)host[i] > worst) worst = host[i], worst_row = i;
+    }
+    out4[0] = host[(sp.off_flag - sp.off_cnt) / 4];
+    out4[1] = total;
+    out4[2] = worst;
+    out4[3] = worst_row;
     return TVBF_OK;
 }
 

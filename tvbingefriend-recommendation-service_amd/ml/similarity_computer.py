@@ -232,7 +232,7 @@ class SimilarityComputer:
         n = int(sources[0][1].shape[0]) - (1 if sources[0][0] == "csr" else 0)
         scales = layout.scales()
         z = engine.assemble_normalize(dev_sources, n, layout.offsets, scales)
-        top = engine.cosine_topk(z, k, min_similarity)
+        top = engine.catalogue_topk(z, k, min_similarity)
         cscales = layout.component_scales()
         zc = z if cscales == scales else engine.assemble_normalize(dev_sources, n, layout.offsets, cscales)
         comp = engine.component_scores(zc, layout.offsets, cscales, top.idx)
