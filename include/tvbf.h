@@ -205,6 +205,52 @@ int tvbf_topk_finish(int64_t nq, int k, int slots, int32_t* out_idx, float* out_
                      int32_t* out_count, const void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * Column side of the incremental form: a row shard that hands the scores it computes to the
+ * shows of the COLUMNS as well, so that of two shards only one computes the block between them
+ * (score(i, j) and score(j, i) are the same products summed in the same order: the score matrix
+ * is symmetric bit for bit).  No counterpart in the reference (single process, one matrix).
+ *
+ *   tvbf_colside            col_bound: device, n_total ordered-float words (the layout of the
+ *                           bounds at the start of a top-K workspace, gathered over all shards,
+ *                           indexed by global column); state / state_bytes: device buffer of
+ *                           tvbf_topk_colside_bytes(n_total, cap) bytes whose first word is the
+ *                           overflow flag; cap: candidates kept per show (<= 1024)
+ *   tvbf_topk_colside_begin clears the counters and the flag
+ *   tvbf_topk_accumulate_ex tvbf_topk_accumulate_f32 plus, with colside != NULL, the column side
+ *                           (d % 64 == 0, k <= 24): a score that reaches col_bound[column] is
+ *                           appended to that column's buffer as (score, global row); with
+ *                           gate != NULL the sweep runs only if *gate != 0 (device word; used
+ *                           for the plain re-run after an overflow) and takes no column side
+ *   tvbf_topk_colside_reduce  the K best buffered candidates of shows row0 .. row0+rows-1 as
+ *                           partial lists (rows x k keys, the workspace slot format) into `lists`
+ *   tvbf_topk_finish_ex     tvbf_topk_finish that also merges n_extra lists of nq x k keys found
+ *                           at extra + e * extra_stride (keys), e.g. those received from the
+ *                           shards that computed this shard's columns; with gate != NULL and
+ *                           *gate != 0 it merges slots alt_first .. alt_first+alt_slots-1 alone
+ */
+typedef struct tvbf_colside {
+    const uint32_t* col_bound;
+    void* state;
+    size_t state_bytes;
+    int64_t n_total;
+    int32_t cap;
+} tvbf_colside;
+
+size_t tvbf_topk_colside_bytes(int64_t n_total, int cap);
+int tvbf_topk_colside_begin(void* state, size_t state_bytes, int64_t n_total, int cap, void* stream);
+int tvbf_topk_accumulate_ex_f32(const float* Zq, int64_t nq, int64_t q_row0, int64_t d, int64_t ld,
+                                const float* ZcA, int64_t nA, int64_t colA, const float* ZcB, int64_t nB,
+                                int64_t colB, int k, float min_similarity, int exclude_self, void* workspace,
+                                size_t workspace_bytes, int slot0, int max_slots, int* slots_used,
+                                const tvbf_colside* colside, const uint32_t* gate, void* stream);
+int tvbf_topk_colside_reduce(const tvbf_colside* colside, int64_t row0, int64_t rows, int k,
+                             float min_similarity, uint64_t* lists, void* stream);
+int tvbf_topk_finish_ex(int64_t nq, int k, int slots, const uint64_t* extra, int n_extra,
+                        int64_t extra_stride, const uint32_t* gate, int alt_first, int alt_slots,
+                        int32_t* out_idx, float* out_score, int32_t* out_count, const void* workspace,
+                        size_t workspace_bytes, void* stream);
+
+/*
  * K2 alone -- the dense score matrix, for callers that want it whole (small n):
  * out[i, j] = sum_c Zq[i, c] * Zall[j, c].  With Z one normalised feature block
  * this is sklearn's cosine_similarity(X) of ml/similarity_computer.py:41,58,86;

@@ -174,3 +174,57 @@ def test_symmetric_benchmark_shape_sample(pkg, device):
     assert torch.equal(sym.count, plain.count)
     assert torch.equal(sym.idx, plain.idx)
     assert torch.equal(sym.score, plain.score)
+
+
+def _lockstep_ranks(device, z, n, world, k, ms, col_cap=512):
+    """All ranks of a symmetric sharded job on one GPU, phase by phase, with the collectives
+    replaced by indexing; returns the concatenated lists and the reduced overflow flag."""
+    import torch
+
+    from tvbingefriend_recommendation_service_amd import engine, sharding
+
+    shards = [sharding.shard_bounds(n, world, r) for r in range(world)]
+    per = shards[0].per_rank
+    z_all = torch.zeros((per * world, z.shape[1]), device=device)
+    z_all[:n] = z[:n]
+    jobs = [sharding.SymmetricShardJob(z_all[r * per : (r + 1) * per], sh, k, ms, col_cap=col_cap)
+            for r, sh in enumerate(shards)]
+    for j in jobs:
+        j.phase_own()
+    bounds_all = torch.cat([j.own_bounds() for j in jobs])  # the all-gather
+    for j in jobs:
+        j.phase_half(z_all, bounds_all)
+    sends = [j.lists_for_peers(bounds_all) for j in jobs]
+    flag = torch.stack([j.flag for j in jobs]).max(dim=0).values.contiguous()  # the max-reduction
+    tops = []
+    for r, j in enumerate(jobs):
+        recv = torch.stack([sends[p][r] for p in range(world)]).contiguous()  # the all-to-all
+        tops.append(j.finish(z_all, recv, flag))
+    torch.cuda.synchronize()
+    cat = lambda f: torch.cat([getattr(t, f)[: sh.rows] for t, sh in zip(tops, shards)])  # noqa: E731
+    return engine.TopK(cat("idx"), cat("score"), cat("count")), int(flag.item())
+
+
+@pytest.mark.parametrize("n,world", [(3000, 2), (3000, 3), (3000, 4), (5000, 8), (2049, 4), (700, 8), (1300, 5), (10, 8)])
+def test_symmetric_sharded_job_equals_plain(pkg, device, n, world):
+    """Every block between two shards is computed by one of them only (the partner block of an
+    even world half by each); the lists equal the single-GPU plain sweep bit for bit."""
+    from tvbingefriend_recommendation_service_amd import engine
+
+    z, _, _ = _z_hybrid(device, n, seed=400 + n + world)
+    for k, ms in ((20, 0.1), (3, 0.25)):
+        plain = engine.cosine_topk(z, k, ms)
+        got, flag = _lockstep_ranks(device, z, n, world, k, ms)
+        assert flag == 0
+        _assert_same(got, plain, f"n={n} world={world} k={k}")
+
+
+def test_symmetric_sharded_job_overflow(pkg, device):
+    """Column buffers of one entry overflow on every rank: all ranks re-run plainly, same lists."""
+    from tvbingefriend_recommendation_service_amd import engine
+
+    z, _, _ = _z_hybrid(device, 2500, seed=12)
+    plain = engine.cosine_topk(z, 20, 0.1)
+    got, flag = _lockstep_ranks(device, z, 2500, 4, 20, 0.1, col_cap=1)
+    assert flag == 1
+    _assert_same(got, plain, "sharded overflow")

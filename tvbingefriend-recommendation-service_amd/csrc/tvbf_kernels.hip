@@ -884,12 +884,12 @@ __device__ static inline void col_append(const TopkArgs& a, unsigned rowg, u64 k
         __hip_atomic_store(a.overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <bool LIST_GLOBAL, int SYM = SYM_OFF>
+template <bool LIST_GLOBAL, int SYM = SYM_OFF, bool COLSIDE = (SYM == SYM_HALF)>
 __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkArgs a) {
     static_assert(BK == 32 && BM == 128 && BN == 128, "the DMA tile loop is written for 128 x 128 x 32 tiles");
     static_assert(SYM == SYM_OFF || !LIST_GLOBAL, "the symmetric sweeps keep their lists in LDS");
-    constexpr bool COLSIDE = SYM == SYM_HALF;
-    if (SYM == SYM_OFF && a.gate && __hip_atomic_load(a.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+    static_assert(!COLSIDE || !LIST_GLOBAL, "the column queue shares LDS with the lists");
+    if (SYM == SYM_OFF && !COLSIDE && a.gate && __hip_atomic_load(a.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
     __shared__ __attribute__((aligned(16))) float tileC0[BN * BK];
     __shared__ __attribute__((aligned(16))) float tileC1[BN * BK];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1317,7 +1317,8 @@ __global__ __launch_bounds__(64 * FIN_ROWS) void topk_finalize_kernel(const u64*
                                                             float* __restrict__ out_score,
                                                             int32_t* __restrict__ out_count,
                                                             const unsigned* __restrict__ gate, int alt_first,
-                                                            int alt_splits) {
+                                                            int alt_splits, const u64* __restrict__ extra,
+                                                            int n_extra, int64_t extra_stride) {
     __shared__ u64 buf[FIN_ROWS][FIN_MAX_KEYS];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -1326,18 +1327,21 @@ __global__ __launch_bounds__(64 * FIN_ROWS) void topk_finalize_kernel(const u64*
     if (gate && *gate != 0u) {
         partial += (int64_t)alt_first * nq * k;
         splits = alt_splits;
+        n_extra = 0;
     }
     u64* b = buf[wave];
-    const int m = splits * k;
+    const int m = (splits + n_extra) * k;
     // gather the non-empty keys of all partial lists, packed (most slots of late splits are empty
-    // because the shared bound rejected their columns)
+    // because the shared bound rejected their columns); `extra` lists (received from other ranks)
+    // have the same format, list e at extra + e * extra_stride
     int packed = 0;
     for (int i0 = 0; i0 < m; i0 += 64) {
         const int i = i0 + lane;
         u64 key = 0ull;
         if (i < m) {
             const int s = i / k;
-            key = partial[((int64_t)s * nq + row) * k + (i - s * k)];
+            key = s < splits ? partial[((int64_t)s * nq + row) * k + (i - s * k)]
+                             : extra[(int64_t)(s - splits) * extra_stride + row * k + (i - s * k)];
         }
         const bool real = (uint32_t)key != 0u;
         const u64 mask = __ballot(real);
@@ -1379,17 +1383,18 @@ __global__ __launch_bounds__(64 * COLRED_ROWS) void col_reduce_kernel(const unsi
                                                                       const u64* __restrict__ col_buf, int col_cap,
                                                                       const unsigned* __restrict__ bound, int64_t n,
                                                                       int k, float min_similarity,
-                                                                      u64* __restrict__ out) {
+                                                                      u64* __restrict__ out, int64_t row0) {
+    // shows row0 .. row0 + n - 1 of the buffers; list i of `out` belongs to show row0 + i
     __shared__ u64 buf[COLRED_ROWS][COL_CAP_MAX];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int64_t row = (int64_t)blockIdx.x * COLRED_ROWS + wave;
     if (row >= n) return;
     u64* b = buf[wave];
-    int m = (int)col_cnt[row];
+    int m = (int)col_cnt[row0 + row];
     if (m > col_cap) m = col_cap;
-    const unsigned thr = bound[row];
-    const u64* src = col_buf + row * col_cap;
+    const unsigned thr = bound[row0 + row];
+    const u64* src = col_buf + (row0 + row) * col_cap;
     int packed = 0;
     for (int i0 = 0; i0 < m; i0 += 64) {
         const int i = i0 + lane;
@@ -1770,6 +1775,20 @@ static int max_merge_slots(int k) { return k < 1 ? 0 : FIN_MAX_KEYS / k; }
 
 static int tiles_of(int64_t n) { return (int)((n + BN - 1) / BN); }
 
+// LDS queue of the column side: what is left of half a CU's LDS beside the lists and the tiles.
+// Returns the entries (0: does not fit) and the dynamic LDS bytes of the kernel.
+static int colside_queue(int k, int64_t d, size_t* lds_bytes) {
+    if (!topk_use_dma(d) || topk_list_global(k)) return 0;
+    const size_t base = topk_lds_bytes(k, d);
+    const size_t fixed = base + topk_static_lds_bytes(d) + BN * sizeof(float) + 16;
+    const size_t room = fixed < 80 * 1024 ? 80 * 1024 - fixed : 0;
+    int q = (int)(room / 12) / 64 * 64;
+    if (q > 1024) q = 1024;
+    if (q < 128) return 0;
+    if (lds_bytes) *lds_bytes = base + BN * sizeof(float) + 16 + (size_t)q * 12;
+    return q;
+}
+
 // workspace = [nq bound words, padded to 16 bytes][slot 0: nq x k keys][slot 1] ...
 static size_t ws_bound_bytes(int64_t nq) { return ((size_t)nq * 4 + 15) / 16 * 16; }
 static size_t ws_slot_bytes(int64_t nq, int k) { return (size_t)nq * (size_t)k * 8; }
@@ -1874,10 +1893,25 @@ static int validate_accumulate(const float* Zq, int64_t nq, int64_t q_row0, int6
     return TVBF_OK;
 }
 
-int tvbf_topk_accumulate_f32(const float* Zq, int64_t nq, int64_t q_row0, int64_t d, int64_t ld, const float* ZcA,
-                             int64_t nA, int64_t colA, const float* ZcB, int64_t nB, int64_t colB, int k,
-                             float min_similarity, int exclude_self, void* workspace, size_t workspace_bytes,
-                             int slot0, int max_slots, int* slots_used, void* stream) {
+// column-side state: [overflow flag, 16 bytes][n_total counters, padded to 16 bytes][n_total x cap keys]
+static size_t cs_cnt_off() { return 16; }
+static size_t cs_buf_off(int64_t n_total) { return 16 + ws_bound_bytes(n_total); }
+
+static int check_colside(const tvbf_colside* cs) {
+    if (!cs->col_bound || !cs->state || ((uintptr_t)cs->state & 15))
+        return fail(TVBF_E_BAD_ARG, "column side: null or misaligned pointer");
+    if (cs->n_total < 1 || cs->cap < 1 || cs->cap > COL_CAP_MAX)
+        return fail(TVBF_E_BAD_ARG, "column side: n_total >= 1 and cap in 1..%d", COL_CAP_MAX);
+    if (cs->state_bytes < cs_buf_off(cs->n_total) + (size_t)cs->n_total * cs->cap * 8)
+        return fail(TVBF_E_BAD_SHAPE, "column side: state smaller than tvbf_topk_colside_bytes()");
+    return TVBF_OK;
+}
+
+static int accumulate_impl(const float* Zq, int64_t nq, int64_t q_row0, int64_t d, int64_t ld, const float* ZcA,
+                           int64_t nA, int64_t colA, const float* ZcB, int64_t nB, int64_t colB, int k,
+                           float min_similarity, int exclude_self, void* workspace, size_t workspace_bytes,
+                           int slot0, int max_slots, int* slots_used, const tvbf_colside* cs, const unsigned* gate,
+                           void* stream) {
     if (!slots_used) return fail(TVBF_E_BAD_ARG, "slots_used must be non-null");
     *slots_used = 0;
     int rc = validate_accumulate(Zq, nq, q_row0, d, ld, ZcA, nA, colA, ZcB, nB, colB, k, min_similarity, workspace,
@@ -1891,17 +1925,30 @@ int tvbf_topk_accumulate_f32(const float* Zq, int64_t nq, int64_t q_row0, int64_
     }
 
     const int tiles = tiles_of(nA) + (nB ? tiles_of(nB) : 0);
-    const Plan p = make_plan(nq, tiles, d, k, device_cus(), max_slots);
+    Plan p = make_plan(nq, tiles, d, k, device_cus(), max_slots);
+    int col_lds = 0;
+    if (cs) {
+        rc = check_colside(cs);
+        if (rc) return rc;
+        if (colA + nA > cs->n_total || colB + nB > cs->n_total)
+            return fail(TVBF_E_BAD_SHAPE, "column side: column ranges must lie inside [0, n_total)");
+        col_lds = colside_queue(k, d, &p.lds_bytes);
+        if (!col_lds)
+            return fail(TVBF_E_BAD_SHAPE, "the column side needs d %% 64 == 0 and k <= 24");
+        if (gate) return fail(TVBF_E_BAD_ARG, "a gated sweep has no column side");
+    }
     const size_t need = ws_bound_bytes(nq) + (size_t)(slot0 + p.splits) * ws_slot_bytes(nq, k);
     if (workspace_bytes < need) return fail(TVBF_E_BAD_SHAPE, "workspace must be >= %zu bytes", need);
     const int64_t grid = (int64_t)p.row_blocks * p.splits;
     if (grid > INT32_MAX) return fail(TVBF_E_BAD_ARG, "too many workgroups");
     const bool list_global = topk_list_global(k), dma = topk_use_dma(d);
+    if (gate && !dma) return fail(TVBF_E_BAD_SHAPE, "a gated sweep needs d %% 64 == 0");
     const void* kernel =
-        dma ? (list_global ? reinterpret_cast<const void*>(cosine_topk_dma_kernel<true>)
-                           : reinterpret_cast<const void*>(cosine_topk_dma_kernel<false>))
-            : (list_global ? reinterpret_cast<const void*>(cosine_tile_kernel<MODE_TOPK_G>)
-                           : reinterpret_cast<const void*>(cosine_tile_kernel<MODE_TOPK>));
+        cs  ? reinterpret_cast<const void*>(cosine_topk_dma_kernel<false, SYM_OFF, true>)
+        : dma ? (list_global ? reinterpret_cast<const void*>(cosine_topk_dma_kernel<true>)
+                             : reinterpret_cast<const void*>(cosine_topk_dma_kernel<false>))
+              : (list_global ? reinterpret_cast<const void*>(cosine_tile_kernel<MODE_TOPK_G>)
+                             : reinterpret_cast<const void*>(cosine_tile_kernel<MODE_TOPK>));
     if (p.lds_bytes > 32 * 1024)
         HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
     TopkArgs a;
@@ -1923,10 +1970,23 @@ int tvbf_topk_accumulate_f32(const float* Zq, int64_t nq, int64_t q_row0, int64_
     a.col_tiles = tiles;
     a.min_similarity = min_similarity;
     a.exclude_self = exclude_self;
+    a.gate = gate;
+    if (cs) {
+        char* st = reinterpret_cast<char*>(cs->state);
+        a.col_bound = cs->col_bound;
+        a.overflow = reinterpret_cast<unsigned*>(st);
+        a.col_cnt = reinterpret_cast<unsigned*>(st + cs_cnt_off());
+        a.col_buf = reinterpret_cast<u64*>(st + cs_buf_off(cs->n_total));
+        a.col_cap = cs->cap;
+        a.col_lds = col_lds;
+    }
 #ifdef TVBF_DIAG_TIMELINE
     if (const char* e = getenv("TVBF_DIAG_BUF")) a.gram = reinterpret_cast<float*>(strtoull(e, nullptr, 0));
 #endif
-    if (dma && list_global)
+    if (cs)
+        hipLaunchKernelGGL((cosine_topk_dma_kernel<false, SYM_OFF, true>), dim3((unsigned)grid), dim3(TOPK_THREADS),
+                           p.lds_bytes, (hipStream_t)stream, a);
+    else if (dma && list_global)
         hipLaunchKernelGGL(cosine_topk_dma_kernel<true>, dim3((unsigned)grid), dim3(TOPK_THREADS), p.lds_bytes,
                            (hipStream_t)stream, a);
     else if (dma)
@@ -1943,6 +2003,86 @@ int tvbf_topk_accumulate_f32(const float* Zq, int64_t nq, int64_t q_row0, int64_
     return TVBF_OK;
 }
 
+int tvbf_topk_accumulate_f32(const float* Zq, int64_t nq, int64_t q_row0, int64_t d, int64_t ld, const float* ZcA,
+                             int64_t nA, int64_t colA, const float* ZcB, int64_t nB, int64_t colB, int k,
+                             float min_similarity, int exclude_self, void* workspace, size_t workspace_bytes,
+                             int slot0, int max_slots, int* slots_used, void* stream) {
+    return accumulate_impl(Zq, nq, q_row0, d, ld, ZcA, nA, colA, ZcB, nB, colB, k, min_similarity, exclude_self,
+                           workspace, workspace_bytes, slot0, max_slots, slots_used, nullptr, nullptr, stream);
+}
+
+int tvbf_topk_accumulate_ex_f32(const float* Zq, int64_t nq, int64_t q_row0, int64_t d, int64_t ld, const float* ZcA,
+                                int64_t nA, int64_t colA, const float* ZcB, int64_t nB, int64_t colB, int k,
+                                float min_similarity, int exclude_self, void* workspace, size_t workspace_bytes,
+                                int slot0, int max_slots, int* slots_used, const tvbf_colside* colside,
+                                const uint32_t* gate, void* stream) {
+    return accumulate_impl(Zq, nq, q_row0, d, ld, ZcA, nA, colA, ZcB, nB, colB, k, min_similarity, exclude_self,
+                           workspace, workspace_bytes, slot0, max_slots, slots_used, colside, gate, stream);
+}
+
+size_t tvbf_topk_colside_bytes(int64_t n_total, int cap) {
+    if (n_total < 1 || cap < 1 || cap > COL_CAP_MAX) return 0;
+    return cs_buf_off(n_total) + (size_t)n_total * cap * 8;
+}
+
+int tvbf_topk_colside_begin(void* state, size_t state_bytes, int64_t n_total, int cap, void* stream) {
+    if (!state || ((uintptr_t)state & 15)) return fail(TVBF_E_BAD_ARG, "null or misaligned state");
+    if (!tvbf_topk_colside_bytes(n_total, cap) || state_bytes < tvbf_topk_colside_bytes(n_total, cap))
+        return fail(TVBF_E_BAD_SHAPE, "state smaller than tvbf_topk_colside_bytes()");
+    const int64_t words = (int64_t)(cs_buf_off(n_total) / 4);  // flag and counters
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<unsigned*>(state), words, 0u);
+    HIP_TRY(hipGetLastError());
+    return TVBF_OK;
+}
+
+int tvbf_topk_colside_reduce(const tvbf_colside* cs, int64_t row0, int64_t rows, int k, float min_similarity,
+                             uint64_t* lists, void* stream) {
+    if (!cs || !lists) return fail(TVBF_E_BAD_ARG, "null pointer argument");
+    int rc = check_colside(cs);
+    if (rc) return rc;
+    if (k < 1 || k > TVBF_MAX_K) return fail(TVBF_E_BAD_ARG, "k must be 1..%d", TVBF_MAX_K);
+    if (row0 < 0 || rows < 0 || row0 + rows > cs->n_total) return fail(TVBF_E_BAD_ARG, "rows outside [0, n_total)");
+    if (rows == 0) return TVBF_OK;
+    if (min_similarity < -FLT_MAX) min_similarity = -FLT_MAX;
+    const char* st = reinterpret_cast<const char*>(cs->state);
+    hipLaunchKernelGGL(col_reduce_kernel, dim3((unsigned)((rows + COLRED_ROWS - 1) / COLRED_ROWS)),
+                       dim3(64 * COLRED_ROWS), 0, (hipStream_t)stream,
+                       reinterpret_cast<const unsigned*>(st + cs_cnt_off()),
+                       reinterpret_cast<const u64*>(st + cs_buf_off(cs->n_total)), (int)cs->cap, cs->col_bound, rows, k,
+                       min_similarity, reinterpret_cast<u64*>(lists), row0);
+    HIP_TRY(hipGetLastError());
+    return TVBF_OK;
+}
+
+int tvbf_topk_finish_ex(int64_t nq, int k, int slots, const uint64_t* extra, int n_extra, int64_t extra_stride,
+                        const uint32_t* gate, int alt_first, int alt_slots, int32_t* out_idx, float* out_score,
+                        int32_t* out_count, const void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_topk_common(nq, k, workspace);
+    if (rc) return rc;
+    if (!out_idx || !out_score || !out_count) return fail(TVBF_E_BAD_ARG, "null pointer argument");
+    if (n_extra < 0 || (n_extra > 0 && (!extra || extra_stride < nq * k)))
+        return fail(TVBF_E_BAD_ARG, "extra lists: null pointer or stride below nq * k");
+    if (slots < 0 || slots + n_extra > max_merge_slots(k))
+        return fail(TVBF_E_BAD_ARG, "slots + n_extra must be 0..%d", max_merge_slots(k));
+    int held = slots;
+    if (gate) {
+        if (alt_first < 0 || alt_slots < 0 || alt_slots > max_merge_slots(k))
+            return fail(TVBF_E_BAD_ARG, "bad alternative slot range");
+        if (alt_first + alt_slots > held) held = alt_first + alt_slots;
+    }
+    if (workspace_bytes < ws_bound_bytes(nq) + (size_t)held * ws_slot_bytes(nq, k))
+        return fail(TVBF_E_BAD_SHAPE, "workspace smaller than the slots it is said to hold");
+    if (nq == 0) return TVBF_OK;
+    const char* ws = reinterpret_cast<const char*>(workspace);
+    hipLaunchKernelGGL(topk_finalize_kernel, dim3((unsigned)((nq + FIN_ROWS - 1) / FIN_ROWS)), dim3(64 * FIN_ROWS), 0,
+                       (hipStream_t)stream, reinterpret_cast<const u64*>(ws + ws_bound_bytes(nq)), nq, k, slots, out_idx,
+                       out_score, out_count, gate, alt_first, alt_slots, reinterpret_cast<const u64*>(extra), n_extra,
+                       extra_stride);
+    HIP_TRY(hipGetLastError());
+    return TVBF_OK;
+}
+
 int tvbf_topk_finish(int64_t nq, int k, int slots, int32_t* out_idx, float* out_score, int32_t* out_count,
                      const void* workspace, size_t workspace_bytes, void* stream) {
     int rc = check_topk_common(nq, k, workspace);
@@ -1956,7 +2096,7 @@ int tvbf_topk_finish(int64_t nq, int k, int slots, int32_t* out_idx, float* out_
     hipLaunchKernelGGL(topk_finalize_kernel, dim3((unsigned)((nq + FIN_ROWS - 1) / FIN_ROWS)), dim3(64 * FIN_ROWS), 0,
                        (hipStream_t)stream,
                        reinterpret_cast<const u64*>(ws + ws_bound_bytes(nq)), nq, k, slots, out_idx, out_score,
-                       out_count, (const unsigned*)nullptr, 0, 0);
+                       out_count, (const unsigned*)nullptr, 0, 0, (const u64*)nullptr, 0, (int64_t)0);
     HIP_TRY(hipGetLastError());
     return TVBF_OK;
 }
@@ -2026,13 +2166,8 @@ static SymPlan make_sym_plan(int64_t n, int64_t d, int k) {
     sp.s_full = full.splits;
     if (sp.s_diag + sp.s_half + 1 > slots || sp.s_full > slots) return sp;
     sp.lds_diag = full.lds_bytes;
-    // the column queue takes what is left of half a CU's LDS beside the lists and the tiles
-    const size_t fixed = full.lds_bytes + topk_static_lds_bytes(d) + BN * sizeof(float) + 16;
-    const size_t room = fixed < 80 * 1024 ? 80 * 1024 - fixed : 0;
-    sp.col_lds = (int)(room / 12) / 64 * 64;
-    if (sp.col_lds > 1024) sp.col_lds = 1024;
-    if (sp.col_lds < 128) return sp;
-    sp.lds_half = full.lds_bytes + BN * sizeof(float) + 16 + (size_t)sp.col_lds * 12;
+    sp.col_lds = colside_queue(k, d, &sp.lds_half);
+    if (!sp.col_lds) return sp;
     sp.col_cap = 1024;
     if (const char* e = getenv("TVBF_SYM_COL_CAP")) sp.col_cap = atoi(e);  // tuning / test aid
     if (sp.col_cap < 1) sp.col_cap = 1;
@@ -2120,7 +2255,7 @@ int tvbf_cosine_topk_sym_f32(const float* Z, int64_t n, int64_t d, int64_t ld, i
                        dim3(TOPK_THREADS), sp.lds_half, st, a);
     hipLaunchKernelGGL(col_reduce_kernel, dim3((unsigned)((n + COLRED_ROWS - 1) / COLRED_ROWS)), dim3(64 * COLRED_ROWS),
                        0, st, col_cnt, col_buf, sp.col_cap, bound, n, k, min_similarity,
-                       lists + (size_t)(sp.s_diag + sp.s_half) * slot_keys);
+                       lists + (size_t)(sp.s_diag + sp.s_half) * slot_keys, (int64_t)0);
     // the complete plain sweep: a no-op unless a buffer overflowed
     const int first_full = sp.s_diag + sp.s_half + 1;
     a.partial = lists + (size_t)first_full * slot_keys;
@@ -2129,7 +2264,8 @@ int tvbf_cosine_topk_sym_f32(const float* Z, int64_t n, int64_t d, int64_t ld, i
     hipLaunchKernelGGL((cosine_topk_dma_kernel<false, SYM_OFF>), dim3((unsigned)(sp.row_blocks * sp.s_full)),
                        dim3(TOPK_THREADS), sp.lds_diag, st, a);
     hipLaunchKernelGGL(topk_finalize_kernel, dim3((unsigned)((n + FIN_ROWS - 1) / FIN_ROWS)), dim3(64 * FIN_ROWS), 0, st,
-                       lists, n, k, first_full, out_idx, out_score, out_count, flag, first_full, sp.s_full);
+                       lists, n, k, first_full, out_idx, out_score, out_count, flag, first_full, sp.s_full,
+                       (const u64*)nullptr, 0, (int64_t)0);
     HIP_TRY(hipGetLastError());
     return TVBF_OK;
 }

@@ -492,7 +492,20 @@ class TopkSession:
             raise ValueError("a column range must be a contiguous (rows >= n, ld) tensor")
         return t.data_ptr(), n, int(col0), t
 
-    def accumulate(self, range_a, range_b=None, max_slots: int = 16) -> int:
+    def bounds(self) -> torch.Tensor:
+        """The per-row lower bounds of the K-th scores (ordered-float words, as an int32 view of
+        the start of the workspace): what a shard publishes for the column side of its peers."""
+        return self.workspace.view(torch.int32)[: self.nq]
+
+    def slot_lists(self) -> torch.Tensor:
+        """The partial lists written so far: (slots used, nq, k) int64 keys (a view of the workspace)."""
+        first = ((self.nq * 4 + 15) // 16 * 16) // 8
+        return self.workspace[first : first + self.used * self.nq * self.k].view(self.used, self.nq, self.k)
+
+    def accumulate(self, range_a, range_b=None, max_slots: int = 16, *, colside=None, gate=None) -> int:
+        """One fused launch over up to two column ranges.  ``colside=(ColumnSide, col_bound)`` also
+        hands the scores to the shows of the columns; ``gate`` (int32 device tensor) makes the
+        sweep conditional on a non-zero word -- the slots are reserved either way."""
         pa, na, ca, keep_a = self._range(range_a, self.ld)
         pb, nb, cb, keep_b = self._range(range_b, self.ld)
         if na + nb == 0 or self.nq == 0:
@@ -503,23 +516,98 @@ class TopkSession:
         import ctypes
 
         used = ctypes.c_int(0)
+        cs_ref = None
+        if colside is not None:
+            side, col_bound = colside
+            cs_ref = ctypes.byref(side.struct(col_bound))
+        gate_ptr = None
+        if gate is not None:
+            _require_cuda(gate, "gate", dtype=torch.int32)
+            gate_ptr = gate.data_ptr()
         with torch.cuda.device(self.dev):
-            rc = self.lib.tvbf_topk_accumulate_f32(
+            rc = self.lib.tvbf_topk_accumulate_ex_f32(
                 self.z_q.data_ptr(), self.nq, self.q_row0, self.ld, self.ld, pa, na, ca, pb, nb, cb, self.k,
                 self.min_similarity, 1 if self.exclude_self else 0, self.workspace.data_ptr(), self.ws_bytes,
-                self.used, budget, ctypes.byref(used), _stream_ptr())
-        native.check(rc, "tvbf_topk_accumulate_f32")
+                self.used, budget, ctypes.byref(used), cs_ref, gate_ptr, _stream_ptr())
+        native.check(rc, "tvbf_topk_accumulate_ex_f32")
         self.used += used.value
         return used.value
 
-    def finish(self, out: TopK | None = None) -> TopK:
+    def finish(self, out: TopK | None = None, *, extra: torch.Tensor | None = None, gate=None,
+               alt: tuple[int, int] | None = None, slots: int | None = None) -> TopK:
+        """Merge the partial lists of slots 0 .. slots-1 (default: all used) and of ``extra``
+        (int64 keys, (lists, rows >= nq, k) contiguous).  With ``gate`` and ``alt=(first, count)``
+        the slots first .. first+count-1 alone are merged when the gate word is non-zero."""
         if out is None:
             out = TopK(torch.empty((self.nq, self.k), dtype=torch.int32, device=self.dev),
                        torch.empty((self.nq, self.k), dtype=torch.float32, device=self.dev),
                        torch.empty((self.nq,), dtype=torch.int32, device=self.dev))
+        if self.nq == 0:  # a rank without rows: nothing to merge
+            return out
+        slots = self.used if slots is None else int(slots)
+        n_extra, stride, extra_ptr = 0, 0, None
+        if extra is not None and extra.numel():
+            _require_cuda(extra, "extra", dtype=torch.int64)
+            if extra.dim() != 3 or not extra.is_contiguous() or extra.shape[2] != self.k or extra.shape[1] < self.nq:
+                raise ValueError("extra must be a contiguous (lists, rows >= nq, k) int64 tensor")
+            n_extra, stride, extra_ptr = extra.shape[0], extra.shape[1] * self.k, extra.data_ptr()
+        gate_ptr, alt_first, alt_slots = None, 0, 0
+        if gate is not None:
+            _require_cuda(gate, "gate", dtype=torch.int32)
+            gate_ptr, (alt_first, alt_slots) = gate.data_ptr(), alt
         with torch.cuda.device(self.dev):
-            rc = self.lib.tvbf_topk_finish(self.nq, self.k, self.used, out.idx.data_ptr(), out.score.data_ptr(),
-                                           out.count.data_ptr(), self.workspace.data_ptr(), self.ws_bytes,
-                                           _stream_ptr())
-        native.check(rc, "tvbf_topk_finish")
+            rc = self.lib.tvbf_topk_finish_ex(self.nq, self.k, slots, extra_ptr, n_extra, stride, gate_ptr,
+                                              alt_first, alt_slots, out.idx.data_ptr(), out.score.data_ptr(),
+                                              out.count.data_ptr(), self.workspace.data_ptr(), self.ws_bytes,
+                                              _stream_ptr())
+        native.check(rc, "tvbf_topk_finish_ex")
+        return out
+
+
+class ColumnSide:
+    """Device state of the column side of a sharded symmetric sweep: per show of the whole
+    catalogue a counter and a buffer of ``cap`` candidates (score, global row of the query side),
+    behind one overflow flag."""
+
+    def __init__(self, n_total: int, device, cap: int = 512):
+        self.lib = native.load()
+        self.n_total, self.cap, self.dev = int(n_total), int(cap), torch.device(device)
+        self.bytes = int(self.lib.tvbf_topk_colside_bytes(self.n_total, self.cap))
+        if not self.bytes:
+            raise ValueError("n_total >= 1 and 1 <= cap <= 1024")
+        self.state = torch.empty((self.bytes + 15) // 16 * 2, dtype=torch.int64, device=self.dev)
+        self._struct = None
+        self.begin()
+
+    def begin(self) -> None:
+        with torch.cuda.device(self.dev):
+            rc = self.lib.tvbf_topk_colside_begin(self.state.data_ptr(), self.bytes, self.n_total, self.cap, _stream_ptr())
+        native.check(rc, "tvbf_topk_colside_begin")
+
+    @property
+    def flag(self) -> torch.Tensor:
+        """The overflow word (int32 view, one element)."""
+        return self.state.view(torch.int32)[:1]
+
+    def struct(self, col_bound: torch.Tensor):
+        _require_cuda(col_bound, "col_bound", dtype=torch.int32)
+        if col_bound.dim() != 1 or col_bound.numel() < self.n_total or not col_bound.is_contiguous():
+            raise ValueError("col_bound must hold n_total contiguous words")
+        self._struct = native.ColSide(col_bound.data_ptr(), self.state.data_ptr(), self.bytes, self.n_total, self.cap)
+        self._keep = col_bound
+        return self._struct
+
+    def reduce(self, col_bound: torch.Tensor, row0: int, rows: int, k: int, min_similarity: float,
+               out: torch.Tensor) -> torch.Tensor:
+        """The K best buffered candidates of shows row0 .. row0+rows-1 as partial lists into
+        ``out`` ((>= rows, k) int64 keys, contiguous)."""
+        import ctypes
+
+        _require_cuda(out, "out", dtype=torch.int64)
+        if out.dim() != 2 or out.shape[1] != k or out.shape[0] < rows or not out.is_contiguous():
+            raise ValueError("out must be a contiguous (>= rows, k) int64 tensor")
+        with torch.cuda.device(self.dev):
+            rc = self.lib.tvbf_topk_colside_reduce(ctypes.byref(self.struct(col_bound)), int(row0), int(rows), int(k),
+                                                   float(min_similarity), out.data_ptr(), _stream_ptr())
+        native.check(rc, "tvbf_topk_colside_reduce")
         return out

@@ -34,6 +34,11 @@ SYMBOLS = (
     "tvbf_topk_begin",
     "tvbf_topk_accumulate_f32",
     "tvbf_topk_finish",
+    "tvbf_topk_colside_bytes",
+    "tvbf_topk_colside_begin",
+    "tvbf_topk_accumulate_ex_f32",
+    "tvbf_topk_colside_reduce",
+    "tvbf_topk_finish_ex",
     "tvbf_query_workspace_bytes",
     "tvbf_query_topk_f32",
     "tvbf_gram_f32",
@@ -59,6 +64,13 @@ class Source(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int32), ("index64", ctypes.c_int32), ("width", ctypes.c_int32),
                 ("z_col", ctypes.c_int32), ("data", ctypes.c_void_p), ("ld", ctypes.c_int64),
                 ("indptr", ctypes.c_void_p), ("indices", ctypes.c_void_p)]
+
+
+class ColSide(ctypes.Structure):
+    """struct tvbf_colside of include/tvbf.h."""
+
+    _fields_ = [("col_bound", ctypes.c_void_p), ("state", ctypes.c_void_p), ("state_bytes", ctypes.c_size_t),
+                ("n_total", ctypes.c_int64), ("cap", ctypes.c_int32)]
 
 
 class NativeLibraryError(RuntimeError):
@@ -134,6 +146,19 @@ def load() -> ctypes.CDLL:
     lib.tvbf_cosine_topk_sym_f32.argtypes = [vp, i64, i64, i64, c.c_int, f32, c.c_int, vp, vp, vp, vp, sz, vp]
     lib.tvbf_cosine_topk_sym_inspect.restype = c.c_int
     lib.tvbf_cosine_topk_sym_inspect.argtypes = [vp, i64, i64, c.c_int, c.POINTER(i64), vp]
+    lib.tvbf_topk_colside_bytes.restype = sz
+    lib.tvbf_topk_colside_bytes.argtypes = [i64, c.c_int]
+    lib.tvbf_topk_colside_begin.restype = c.c_int
+    lib.tvbf_topk_colside_begin.argtypes = [vp, sz, i64, c.c_int, vp]
+    lib.tvbf_topk_accumulate_ex_f32.restype = c.c_int
+    lib.tvbf_topk_accumulate_ex_f32.argtypes = [vp, i64, i64, i64, i64, vp, i64, i64, vp, i64, i64, c.c_int, f32,
+                                                c.c_int, vp, sz, c.c_int, c.c_int, c.POINTER(c.c_int),
+                                                c.POINTER(ColSide), vp, vp]
+    lib.tvbf_topk_colside_reduce.restype = c.c_int
+    lib.tvbf_topk_colside_reduce.argtypes = [c.POINTER(ColSide), i64, i64, c.c_int, f32, vp, vp]
+    lib.tvbf_topk_finish_ex.restype = c.c_int
+    lib.tvbf_topk_finish_ex.argtypes = [i64, c.c_int, c.c_int, vp, c.c_int, i64, vp, c.c_int, c.c_int, vp, vp, vp,
+                                        vp, sz, vp]
     lib.tvbf_component_scores_f32.restype = c.c_int
     lib.tvbf_component_scores_f32.argtypes = [vp, i64, vp, i64, i64, c.POINTER(i32), c.POINTER(f32), c.c_int,
                                               vp, c.c_int, vp, vp]

@@ -119,3 +119,234 @@ def sharded_topk(x_shard: torch.Tensor, offsets, scales, shard: Shard, k: int, m
     work.wait()                                              # the current stream now waits for the gather
     session.accumulate((z_all[after[0]:], after[1], after[0]), (z_all, before[1], before[0]))
     return session.finish(), z_all
+
+
+# ---------------------------------------------------------------------------
+# Symmetric sharded sweep: of two shards only one computes the block between them.
+# ---------------------------------------------------------------------------
+PAD_BOUND = -8388608  # int32 view of the ordered-float word of +inf: a padding row accepts nothing
+
+
+def half_peers(world: int, rank: int) -> list[int]:
+    """The shards whose block with shard ``rank`` is computed BY ``rank`` in full: the
+    (world - 1) // 2 shards that follow it cyclically.  For an even world the block with the shard
+    at distance world / 2 (the partner) is split between the two, see partner_split()."""
+    return [(rank + 1 + i) % world for i in range((world - 1) // 2)]
+
+
+def partner(world: int, rank: int):
+    """The shard at distance world / 2 for an even world, else None."""
+    return (rank + world // 2) % world if world % 2 == 0 else None
+
+
+def partner_split(shard: Shard, upper_rank: int) -> int:
+    """Rows [0, h0) of the UPPER partner's shard are columns of the lower partner's sweep; its rows
+    [h0, rows) are query rows of a second sweep of the upper partner against the lower partner's
+    columns.  h0 is half the shard, rounded up to whole 128-row blocks."""
+    rows = shard_bounds(shard.n, shard.world, upper_rank).rows
+    return min(rows, ((rows + 1) // 2 + 127) // 128 * 128)
+
+
+def half_pieces(shard: Shard):
+    """Column ranges of the main sweep's column side as at most two (first_row, n_rows) pieces of
+    the gathered matrix: the shards of half_peers() and, for the lower partner of an even world,
+    the first partner_split() rows of its partner (cyclically contiguous); padding rows left out."""
+    W, r, P, n = shard.world, shard.rank, shard.per_rank, shard.n
+    peers = half_peers(W, r)
+    tail = 0  # rows of the partner that follow the full peers
+    pt = partner(W, r)
+    if pt is not None and r < W // 2:
+        tail = partner_split(shard, pt)
+    if not peers and not tail:
+        return (0, 0), (0, 0)
+    first = (r + 1) % W
+    end_shard = first + len(peers)  # exclusive, not wrapped
+
+    def span(a_row, b_row):
+        a_row, b_row = min(a_row, n), min(b_row, n)
+        return (a_row, max(0, b_row - a_row))
+
+    if end_shard <= W:  # no wrap (a lower partner never wraps: its partner comes right after the peers)
+        return span(first * P, end_shard * P + tail), (0, 0)
+    return span(first * P, W * P), span(0, (end_shard - W) * P)
+
+
+class SymmetricShardJob:
+    """One rank's side of the symmetric sharded sweep, as phases between which the caller runs the
+    collectives (sharded_topk_symmetric does; a test can drive several simulated ranks in lockstep):
+
+        phase_own()            own rows x own columns (overlaps the all-gather of Z)
+        own_bounds()           -> (per_rank,) int32 words to all-gather
+        phase_half(z_all, b)   own rows x the columns of half_pieces(), rows AND columns fed; the
+                               upper partner of an even world also sweeps its rows [h0, rows)
+                               against its partner's columns
+        lists_for_peers(b)     -> (world, per_rank, k) int64: per peer the lists of ITS rows found here
+        flag                   -> overflow word, to be max-reduced over the ranks
+        finish(z_all, recv, flag) gated plain re-run + merge of own lists and the received ones
+    """
+
+    def __init__(self, z_shard: torch.Tensor, shard: Shard, k: int, min_similarity: float, *, col_cap: int = 512,
+                 slots: int = 64, workspace: torch.Tensor | None = None, colside=None):
+        from . import engine
+
+        self.engine, self.shard, self.k, self.min_similarity = engine, shard, int(k), float(min_similarity)
+        self.z_shard = z_shard
+        self.dev = z_shard.device
+        self.session = engine.TopkSession(z_shard, shard.rows, shard.row0, k, min_similarity, slots=slots,
+                                          workspace=workspace)
+        self.side = colside if colside is not None else engine.ColumnSide(shard.padded_total, self.dev, cap=col_cap)
+        if colside is not None:
+            self.side.begin()
+        self.normal_slots = 0
+        # upper partner: second sweep over the rows [h0, rows) of this shard
+        self.sub, self.h0 = None, 0
+        pt = partner(shard.world, shard.rank)
+        if pt is not None and shard.rank >= shard.world // 2:
+            self.h0 = partner_split(shard, shard.rank)
+            if shard.rows - self.h0 > 0:
+                self.sub = engine.TopkSession(z_shard[self.h0:], shard.rows - self.h0, shard.row0 + self.h0, k,
+                                              min_similarity, slots=16)
+
+    def phase_own(self):
+        own, _, _ = column_pieces(self.shard)
+        self.session.accumulate((self.z_shard, own[1], own[0]))
+
+    def own_bounds(self) -> torch.Tensor:
+        b = torch.full((self.shard.per_rank,), PAD_BOUND, dtype=torch.int32, device=self.dev)
+        if self.shard.rows:
+            b[: self.shard.rows] = self.session.bounds()
+        return b
+
+    def phase_half(self, z_all: torch.Tensor, bounds_all: torch.Tensor):
+        a, b = half_pieces(self.shard)
+        self.session.accumulate((z_all[a[0]:], a[1], a[0]), (z_all[b[0]:], b[1], b[0]),
+                                colside=(self.side, bounds_all))
+        self.normal_slots = self.session.used
+        if self.sub is not None:
+            sh = self.shard
+            pt = partner(sh.world, sh.rank)
+            c0 = min(pt * sh.per_rank, sh.n)
+            cols = min((pt + 1) * sh.per_rank, sh.n) - c0
+            self.sub.bounds().copy_(self.session.bounds()[self.h0:])  # start from what the own block found
+            self.sub.accumulate((z_all[c0:], cols, c0), colside=(self.side, bounds_all))
+
+    def lists_for_peers(self, bounds_all: torch.Tensor) -> torch.Tensor:
+        sh = self.shard
+        send = torch.zeros((sh.world, sh.per_rank, self.k), dtype=torch.int64, device=self.dev)  # zero = empty slot
+        if sh.rows == 0:
+            return send
+        fed = list(half_peers(sh.world, sh.rank))
+        pt = partner(sh.world, sh.rank)
+        if pt is not None:
+            fed.append(pt)
+        for p in fed:
+            r0 = min(p * sh.per_rank, sh.n)
+            rows = min((p + 1) * sh.per_rank, sh.n) - r0
+            if rows > 0:
+                self.side.reduce(bounds_all, r0, rows, self.k, self.min_similarity, send[p])
+        return send
+
+    @property
+    def flag(self) -> torch.Tensor:
+        return self.side.flag
+
+    def finish(self, z_all: torch.Tensor, recv: torch.Tensor, flag: torch.Tensor, out=None):
+        """``flag``: the overflow word after the max-reduction (int32 device tensor).  The plain
+        sweep over all columns is launched in any case and returns at once while the flag is 0."""
+        sh = self.shard
+        own, after, before = column_pieces(sh)
+        first = self.session.used
+        self.session.accumulate((self.z_shard, own[1], own[0]), gate=flag)
+        self.session.accumulate((z_all[after[0]:], after[1], after[0]), (z_all, before[1], before[0]), gate=flag)
+        extra = recv
+        if self.sub is not None and self.sub.used:
+            # the second sweep's lists, placed at the rows they belong to
+            mine = torch.zeros((self.sub.used, sh.per_rank, self.k), dtype=torch.int64, device=self.dev)
+            mine[:, self.h0 : sh.rows] = self.sub.slot_lists()
+            extra = torch.cat([recv, mine], dim=0)
+        return self.session.finish(out, extra=extra, gate=flag, alt=(first, self.session.used - first),
+                                   slots=self.normal_slots)
+
+
+def _via_host(t: torch.Tensor, group) -> bool:
+    return t.is_cuda and dist.get_backend(group) == "gloo"  # gloo: CPU tensors only
+
+
+def gather_words(local: torch.Tensor, world: int, group=None) -> torch.Tensor:
+    """all-gather of equally sized 1-D tensors, rank-major."""
+    if _via_host(local, group):
+        host = local.cpu()
+        parts = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(parts, host, group=group)
+        return torch.cat(parts).to(local.device)
+    out = torch.empty((world * local.numel(),), dtype=local.dtype, device=local.device)
+    if local.is_cuda:
+        dist.all_gather_into_tensor(out, local, group=group)
+    else:
+        dist.all_gather(list(out.chunk(world)), local, group=group)
+    return out
+
+
+def exchange_lists(send: torch.Tensor, group=None) -> torch.Tensor:
+    """all-to-all of (world, ...) tensors: slice p goes to rank p; returns what the ranks sent here."""
+    if _via_host(send, group):
+        host = send.cpu()
+        recv = torch.empty_like(host)
+        dist.all_to_all(list(recv.unbind(0)), [c.contiguous() for c in host.unbind(0)], group=group)
+        return recv.to(send.device)
+    recv = torch.empty_like(send)
+    if send.is_cuda:
+        dist.all_to_all_single(recv, send, group=group)
+    else:
+        dist.all_to_all(list(recv.unbind(0)), [c.contiguous() for c in send.unbind(0)], group=group)
+    return recv
+
+
+def reduce_flag(flag: torch.Tensor, group=None) -> torch.Tensor:
+    """max over the ranks of a one-word tensor (a copy; the input is left alone)."""
+    if _via_host(flag, group):
+        host = flag.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.MAX, group=group)
+        return host.to(flag.device)
+    out = flag.clone()
+    dist.all_reduce(out, op=dist.ReduceOp.MAX, group=group)
+    return out
+
+
+def sharded_topk_symmetric(x_shard: torch.Tensor, offsets, scales, shard: Shard, k: int, min_similarity: float,
+                           group=None, normalize_fn=None, job_fn=None):
+    """sharded_topk with every block between two shards computed once: normalise own rows ->
+    all-gather of Z (asynchronous) -> own block -> all-gather of the per-row bounds -> blocks of the
+    cyclically following half of the shards, rows and columns fed -> all-to-all of the column-side
+    lists (world x per_rank x k keys) -> merge.  Same lists as sharded_topk, bit for bit.
+    Needs a row length that is a multiple of 64 and k <= 24 (the engine raises otherwise)."""
+    if normalize_fn is None:
+        from . import engine
+
+        normalize_fn = engine.normalize_blocks
+    job_fn = job_fn or SymmetricShardJob
+    if x_shard.shape[0] != shard.per_rank:
+        raise ValueError("x_shard must be padded to per_rank rows")
+    z_shard = normalize_fn(x_shard, offsets, scales)
+    z_all = torch.empty((shard.padded_total, z_shard.shape[1]), dtype=z_shard.dtype, device=z_shard.device)
+    host_route = _via_host(z_shard, group)
+    if host_route:
+        host = z_shard.cpu()
+        parts = [torch.empty_like(host) for _ in range(shard.world)]
+        dist.all_gather(parts, host, group=group)
+        z_all.copy_(torch.cat(parts, dim=0))
+        work = None
+    elif z_shard.is_cuda:
+        work = dist.all_gather_into_tensor(z_all, z_shard, group=group, async_op=True)
+    else:
+        work = dist.all_gather(list(z_all.chunk(shard.world, dim=0)), z_shard, group=group, async_op=True)
+    job = job_fn(z_shard, shard, k, min_similarity)
+    job.phase_own()                                       # runs while the shards travel
+    bounds_all = gather_words(job.own_bounds(), shard.world, group)
+    if work is not None:
+        work.wait()
+    job.phase_half(z_all, bounds_all)
+    send = job.lists_for_peers(bounds_all)
+    flag = reduce_flag(job.flag, group)
+    recv = exchange_lists(send, group)
+    return job.finish(z_all, recv, flag), z_all
