@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo is a rehearsal mode: the shards are exchanged through host memory")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline sample")
+    ap.add_argument("--check", action="store_true",
+                    help="after the timed steps, recompute this rank's lists with the plain sweep and compare bitwise")
     ap.add_argument("--sweep", choices=["auto", "plain", "symmetric"], default="auto",
                     help="single GPU: 'symmetric' computes every pair of shows once (identical lists); "
                          "auto takes it whenever the library accepts the shape")
@@ -182,12 +184,18 @@ def main():
     slots = 16 if world == 1 else 32
     ws_bytes = int(native.load().tvbf_topk_workspace_bytes_for_slots(max(nq, 1), args.k, slots))
     workspace = torch.empty((ws_bytes + 15) // 16 * 2, dtype=torch.int64, device=dev)
-    sym_bytes = engine.symmetric_workspace_bytes(nq, ld, args.k) if world == 1 and args.sweep != "plain" else 0
+    sym_bytes = engine.symmetric_workspace_bytes(args.n, ld, args.k) if args.sweep != "plain" else 0
     if args.sweep == "symmetric" and not sym_bytes:
-        raise SystemExit("--sweep symmetric: one GPU, row length a multiple of 64 and k <= 24 only")
+        raise SystemExit("--sweep symmetric: row length a multiple of 64, k <= 24 and >= 256 shows only")
     symmetric = sym_bytes > 0
-    if symmetric:
+    side = None
+    if symmetric and world == 1:
         workspace = torch.empty((sym_bytes + 15) // 16 * 2, dtype=torch.int64, device=dev)
+    elif symmetric:  # sharded: lists of the own, half and (gated) plain sweeps; column buffers of all shows
+        slots = 64
+        ws_bytes = int(native.load().tvbf_topk_workspace_bytes_for_slots(max(nq, 1), args.k, slots))
+        workspace = torch.empty((ws_bytes + 15) // 16 * 2, dtype=torch.int64, device=dev)
+        side = engine.ColumnSide(shard.padded_total, dev, cap=512)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     kernel_ms = []
     own, after, before = sharding.column_pieces(shard)
@@ -214,10 +222,23 @@ def main():
     def step(timed):
         engine.normalize_blocks(x, offsets, scales, out=z_shard)
         work = start_gather()
-        if symmetric:
+        if symmetric and world == 1:
             if timed:
                 ev[0].record()
             engine.cosine_topk_symmetric(z_shard, args.k, min_sim, n=nq, workspace=workspace, out=out)
+        elif symmetric:
+            job = sharding.SymmetricShardJob(z_shard, shard, args.k, min_sim, slots=slots, workspace=workspace,
+                                             colside=side)
+            if timed:
+                ev[0].record()
+            job.phase_own()  # overlaps the all-gather of Z
+            bounds_all = sharding.gather_words(job.own_bounds(), world)
+            work.wait()
+            job.phase_half(z_all, bounds_all)
+            send = job.lists_for_peers(bounds_all)
+            flag = sharding.reduce_flag(job.flag)
+            recv = sharding.exchange_lists(send)
+            job.finish(z_all, recv, flag, out)
         else:
             session = engine.TopkSession(z_shard, nq, shard.row0, args.k, min_sim, slots=slots, workspace=workspace)
             if timed:
@@ -260,6 +281,18 @@ def main():
     else:
         kernel_avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
 
+    if args.check and nq:
+        ref = engine.TopkSession(z_shard, nq, shard.row0, args.k, min_sim)
+        ref.accumulate((z_shard, own[1], own[0]))
+        if world > 1:
+            ref.accumulate((z_all[after[0]:], after[1], after[0]), (z_all, before[1], before[0]))
+        want = ref.finish()
+        torch.cuda.synchronize()
+        same = all(torch.equal(getattr(out, f), getattr(want, f)) for f in ("idx", "score", "count"))
+        print(f"[rank {rank}] lists equal to the plain sweep: {same}", file=sys.stderr, flush=True)
+        if not same:
+            raise SystemExit(3)
+
     pairs = float(args.n) * float(args.n) * args.steps
     # dominant kernel: 2*D flops per ordered pair, nq*n pairs per launch on this rank
     per_rank_rows = shard.per_rank if world > 1 else nq
@@ -288,13 +321,17 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": workload, "rows_per_gpu": per_rank_rows,
-                   "parallelism": f"row-shard x{world} + all-gather ({args.backend})" if world > 1 else "single GPU",
+                   "parallelism": (f"row-shard x{world} + all-gather ({args.backend})"
+                                   + (" + all-to-all of column-side lists" if symmetric else "")) if world > 1 else "single GPU",
                    "sweep": "symmetric: every unordered pair of shows computed once, both shows' lists fed from it; "
                             "flops counted as 2*N^2*D all the same" if symmetric else "plain: every ordered pair computed"},
         "topk_build_time_s": elapsed / args.steps,
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                     "kernel": ("cosine_topk_dma_kernel<false, 1> + <false, 2> (own-shard and half sweeps of the symmetric "
+                     "kernel": ("cosine_topk_dma_kernel<false, 0, false> + <false, 0, true> (own block and half sweep of the "
+                                "symmetric sharded route; HIP events span the collectives between them as well)"
+                                if symmetric and world > 1 else
+                                "cosine_topk_dma_kernel<false, 1> + <false, 2> (own-shard and half sweeps of the symmetric "
                                 "route; HIP events span the whole call: fills, column-buffer reduction, list merge)"
                                 if symmetric else
                                 "cosine_topk_dma_kernel<false, 0> (HIP events also span the 4 us bound fill and the "

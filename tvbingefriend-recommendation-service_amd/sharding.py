@@ -288,18 +288,18 @@ def gather_words(local: torch.Tensor, world: int, group=None) -> torch.Tensor:
 
 
 def exchange_lists(send: torch.Tensor, group=None) -> torch.Tensor:
-    """all-to-all of (world, ...) tensors: slice p goes to rank p; returns what the ranks sent here."""
-    if _via_host(send, group):
-        host = send.cpu()
-        recv = torch.empty_like(host)
-        dist.all_to_all(list(recv.unbind(0)), [c.contiguous() for c in host.unbind(0)], group=group)
-        return recv.to(send.device)
-    recv = torch.empty_like(send)
-    if send.is_cuda:
+    """all-to-all of (world, ...) tensors: slice p goes to rank p; returns what the ranks sent here.
+    RCCL runs one all_to_all_single; gloo has no all-to-all, so CPU tensors (and GPU tensors of a
+    gloo group, through host memory) are all-gathered whole and the slices for this rank picked."""
+    if send.is_cuda and not _via_host(send, group):
+        recv = torch.empty_like(send)
         dist.all_to_all_single(recv, send, group=group)
-    else:
-        dist.all_to_all(list(recv.unbind(0)), [c.contiguous() for c in send.unbind(0)], group=group)
-    return recv
+        return recv
+    host = send.cpu() if send.is_cuda else send
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    parts = [torch.empty_like(host) for _ in range(world)]
+    dist.all_gather(parts, host.contiguous(), group=group)
+    return torch.stack([parts[p][rank] for p in range(world)]).to(send.device)
 
 
 def reduce_flag(flag: torch.Tensor, group=None) -> torch.Tensor:
