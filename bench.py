@@ -192,10 +192,10 @@ def main():
     if symmetric and world == 1:
         workspace = torch.empty((sym_bytes + 15) // 16 * 2, dtype=torch.int64, device=dev)
     elif symmetric:  # sharded: lists of the own, half and (gated) plain sweeps; column buffers of all shows
-        slots = 64
+        slots = 96
         ws_bytes = int(native.load().tvbf_topk_workspace_bytes_for_slots(max(nq, 1), args.k, slots))
         workspace = torch.empty((ws_bytes + 15) // 16 * 2, dtype=torch.int64, device=dev)
-        side = engine.ColumnSide(shard.padded_total, dev, cap=512)
+        side = engine.ColumnSide(shard.padded_total, dev, cap=1024)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     kernel_ms = []
     own, after, before = sharding.column_pieces(shard)

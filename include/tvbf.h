@@ -210,15 +210,15 @@ int tvbf_topk_finish(int64_t nq, int k, int slots, int32_t* out_idx, float* out_
  * (score(i, j) and score(j, i) are the same products summed in the same order: the score matrix
  * is symmetric bit for bit).  No counterpart in the reference (single process, one matrix).
  *
- *   tvbf_colside            col_bound: device, n_total ordered-float words (the layout of the
- *                           bounds at the start of a top-K workspace, gathered over all shards,
- *                           indexed by global column); state / state_bytes: device buffer of
+ *   tvbf_colside            col_bound: device, n_total 64-bit keys (the per-row bounds that
+ *                           start a top-K workspace: the best known lower bound of each row's
+ *                           K-th key, gathered over all shards, indexed by global column); state / state_bytes: device buffer of
  *                           tvbf_topk_colside_bytes(n_total, cap) bytes whose first word is the
  *                           overflow flag; cap: candidates kept per show (<= 1024)
  *   tvbf_topk_colside_begin clears the counters and the flag
  *   tvbf_topk_accumulate_ex tvbf_topk_accumulate_f32 plus, with colside != NULL, the column side
- *                           (d % 64 == 0, k <= 24): a score that reaches col_bound[column] is
- *                           appended to that column's buffer as (score, global row); with
+ *                           (d % 64 == 0, k <= 24): a (score, global row) key above col_bound[column]
+ *                           is appended to that column's buffer; with
  *                           gate != NULL the sweep runs only if *gate != 0 (device word; used
  *                           for the plain re-run after an overflow) and takes no column side
  *   tvbf_topk_colside_reduce  the K best buffered candidates of shows row0 .. row0+rows-1 as
@@ -229,13 +229,24 @@ int tvbf_topk_finish(int64_t nq, int k, int slots, int32_t* out_idx, float* out_
  *                           *gate != 0 it merges slots alt_first .. alt_first+alt_slots-1 alone
  */
 typedef struct tvbf_colside {
-    const uint32_t* col_bound;
+    const uint64_t* col_bound;
     void* state;
     size_t state_bytes;
     int64_t n_total;
     int32_t cap;
 } tvbf_colside;
 
+/*
+ * tvbf_topk_accumulate_sym_f32: the block of a shard's rows against ITS OWN columns
+ * (columns q_row0 .. q_row0+nq-1 = the rows of Zq), every pair computed once, inside an
+ * incremental sequence.  Uses the column-side state at the shard's global rows (col_bound of
+ * the descriptor is not read: the bounds are the workspace's own) and writes *slots_used
+ * lists.  Needs d % 64 == 0, k <= 24, nq >= 2048, max_slots >= 3.
+ */
+int tvbf_topk_accumulate_sym_f32(const float* Zq, int64_t nq, int64_t q_row0, int64_t d, int64_t ld, int k,
+                                 float min_similarity, int exclude_self, void* workspace,
+                                 size_t workspace_bytes, int slot0, int max_slots, int* slots_used,
+                                 const tvbf_colside* colside, void* stream);
 size_t tvbf_topk_colside_bytes(int64_t n_total, int cap);
 int tvbf_topk_colside_begin(void* state, size_t state_bytes, int64_t n_total, int cap, void* stream);
 int tvbf_topk_accumulate_ex_f32(const float* Zq, int64_t nq, int64_t q_row0, int64_t d, int64_t ld,

@@ -176,7 +176,7 @@ def test_symmetric_benchmark_shape_sample(pkg, device):
     assert torch.equal(sym.score, plain.score)
 
 
-def _lockstep_ranks(device, z, n, world, k, ms, col_cap=512):
+def _lockstep_ranks(device, z, n, world, k, ms, col_cap=1024):
     """All ranks of a symmetric sharded job on one GPU, phase by phase, with the collectives
     replaced by indexing; returns the concatenated lists and the reduced overflow flag."""
     import torch
@@ -205,7 +205,8 @@ def _lockstep_ranks(device, z, n, world, k, ms, col_cap=512):
     return engine.TopK(cat("idx"), cat("score"), cat("count")), int(flag.item())
 
 
-@pytest.mark.parametrize("n,world", [(3000, 2), (3000, 3), (3000, 4), (5000, 8), (2049, 4), (700, 8), (1300, 5), (10, 8)])
+@pytest.mark.parametrize("n,world", [(3000, 2), (3000, 3), (3000, 4), (5000, 8), (2049, 4), (700, 8), (1300, 5), (10, 8),
+                                     (9000, 2), (9100, 4), (13000, 3)])  # the last three: own blocks large enough for the inner symmetric sweep
 def test_symmetric_sharded_job_equals_plain(pkg, device, n, world):
     """Every block between two shards is computed by one of them only (the partner block of an
     even world half by each); the lists equal the single-GPU plain sweep bit for bit."""

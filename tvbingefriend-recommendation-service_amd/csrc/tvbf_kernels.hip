@@ -156,7 +156,7 @@ struct TopkArgs {
     const float* zq;
     ColRange rng[2];
     u64* partial;  // [splits][nq][k], first partial slot of this launch
-    unsigned* bound;  // [nq] best known lower bound of every row's K-th score (ordered bits)
+    u64* bound;  // [nq] best known lower bound of every row's K-th KEY (score word and column word)
     int64_t nq, q_row0, ld;
     int d, k, cap;
     int row_blocks, splits, col_tiles;
@@ -174,7 +174,7 @@ struct TopkArgs {
     int shards;
     // column side of a tile: a score that reaches the bound of its COLUMN's show is appended to
     // that show's buffer -- the pair is then never computed with the roles swapped
-    const unsigned* col_bound;  // [shows] lower bounds of the K-th scores (ordered bits), by global row
+    const u64* col_bound;       // [shows] lower bounds of the K-th keys, by global row
     unsigned* col_cnt;          // [shows] entries appended (may exceed col_cap: the rest was dropped)
     u64* col_buf;               // [shows][col_cap] keys (score, global row of the QUERY side)
     int col_cap, col_lds;       // entries per show; entries of the workgroup's LDS queue
@@ -217,7 +217,7 @@ __device__ static inline f32x4 load_chunk(const char* p) {
 // hint only: stale or missing values change how much work is skipped, never
 // which neighbours are kept.
 __device__ static inline void compact_row(u64* buf, unsigned* cnt, u64* mkey, int k, int cap, int lane,
-                                          unsigned* gbound) {
+                                          u64* gbound) {
     int valid = (int)*cnt;
     if (valid > cap) valid = cap;
     valid = __builtin_amdgcn_readfirstlane(valid);
@@ -249,11 +249,11 @@ __device__ static inline void compact_row(u64* buf, unsigned* cnt, u64* mkey, in
     if (has1 && r1 < k) buf[r1] = my1;
     if (has0 && r0 == k - 1) {
         *mkey = my0;
-        if (gbound) atomicMax(gbound, (unsigned)(my0 >> 32));
+        if (gbound) atomicMax(reinterpret_cast<unsigned long long*>(gbound), (unsigned long long)my0);
     }
     if (has1 && r1 == k - 1) {
         *mkey = my1;
-        if (gbound) atomicMax(gbound, (unsigned)(my1 >> 32));
+        if (gbound) atomicMax(reinterpret_cast<unsigned long long*>(gbound), (unsigned long long)my1);
     }
     if (lane == 0) *cnt = (unsigned)(valid < k ? valid : k);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -269,7 +269,7 @@ __device__ static inline void compact_row(u64* buf, unsigned* cnt, u64* mkey, in
 // shared by the waves of a CU and written through, and no cache maintenance is needed (wider
 // scopes would write back and invalidate the XCD's L2 on every merge).
 __device__ static inline void merge_row_global(u64* stg, unsigned* cnt, u64* mkey, u64* glist, u64* scr, int k,
-                                               int cap, int lane, unsigned* gbound, u64 empty) {
+                                               int cap, int lane, u64* gbound, u64 empty) {
     int valid = (int)*cnt;
     if (valid > cap) valid = cap;
     valid = __builtin_amdgcn_readfirstlane(valid);
@@ -317,7 +317,7 @@ __device__ static inline void merge_row_global(u64* stg, unsigned* cnt, u64* mke
         if (real[u] && rk[u] < k) __hip_atomic_store(glist + rk[u], my[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (real[u] && rk[u] == k - 1) {
             *mkey = my[u];
-            if (gbound) atomicMax(gbound, (unsigned)(my[u] >> 32));
+            if (gbound) atomicMax(reinterpret_cast<unsigned long long*>(gbound), (unsigned long long)my[u]);
         }
     }
     for (int j = n_real + lane; j < k; j += 64) __hip_atomic_store(glist + j, empty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
     float gbf = a.min_similarity;                        // last value read from the global bound
     // padded rows (>= nq) repeat the last real row but without its self exclusion:
     // they neither read nor publish bounds
-    unsigned* my_gb = (!GRAM && q0 + lrow < a.nq) ? a.bound + q0 + lrow : nullptr;
+    unsigned* my_gb = (!GRAM && q0 + lrow < a.nq) ? reinterpret_cast<unsigned*>(a.bound + q0 + lrow) + 1 : nullptr;  // score word
 
     // ---- staging geometry: thread -> (row r + 32 i, 16-byte chunk c) ----
     const int sc = tid & 7;
@@ -899,8 +899,9 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
     float* scratch_all = reinterpret_cast<float*>(cnt_all + BM);           // [4][DMA_SLOTS * 64]
     u64* merge_scr = reinterpret_cast<u64*>(scratch_all + 4 * DMA_SLOTS * 64);  // [4][k + cap], global lists only
     // column side (same place as merge_scr, which only the global lists use)
-    float* cbound = scratch_all + 4 * DMA_SLOTS * 64;                      // [BN] bounds of the tile's column shows
-    unsigned* lcnt = reinterpret_cast<unsigned*>(cbound + BN);             // entries queued (4 words reserved)
+    float* cbound = scratch_all + 4 * DMA_SLOTS * 64;                      // [BN] bound keys of the tile's column shows: score parts
+    unsigned* cblo = reinterpret_cast<unsigned*>(cbound + BN);             // [BN] ... and column words
+    unsigned* lcnt = cblo + BN;                                            // entries queued (4 words reserved)
     u64* lkey = reinterpret_cast<u64*>(lcnt + 4);                          // [col_lds]
     unsigned* lrowg = reinterpret_cast<unsigned*>(lkey + (COLSIDE ? a.col_lds : 0));  // [col_lds]
 
@@ -916,7 +917,7 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
     int col_tiles = a.col_tiles;
     if (SYM != SYM_OFF) {
         // shard s = row blocks [s * row_blocks / shards, (s + 1) * row_blocks / shards): sizes differ by one block at most
-        const int64_t n_all = a.rng[0].n;
+        const int64_t n_all = a.rng[0].n, base0 = a.rng[0].col_base;
         const float* z_all = a.rng[0].z;
         const int64_t ld = a.ld;
         const int RB = a.row_blocks, V = a.shards;
@@ -924,7 +925,7 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
             const int64_t r0 = (int64_t)(((int64_t)first * RB) / V) * BM;
             int64_t r1 = (int64_t)(((int64_t)(first + count) * RB) / V) * BM;
             if (r1 > n_all) r1 = n_all;
-            return ColRange{z_all + r0 * ld, r1 - r0, r0, (int)((r1 - r0 + BN - 1) / BN)};
+            return ColRange{z_all + r0 * ld, r1 - r0, base0 + r0, (int)((r1 - r0 + BN - 1) / BN)};
         };
         const int v = (int)((((int64_t)rb + 1) * V - 1) / RB);
         if (SYM == SYM_DIAG) {
@@ -968,7 +969,7 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
     u64 mkey = dead_row ? ~0ull : sentinel_key(a.min_similarity);
     float thr = dead_row ? INFINITY : a.min_similarity;
     float gbf = a.min_similarity;
-    unsigned* my_gb = (q0 + lrow < a.nq) ? a.bound + q0 + lrow : nullptr;
+    unsigned* my_gb = (q0 + lrow < a.nq) ? reinterpret_cast<unsigned*>(a.bound + q0 + lrow) + 1 : nullptr;  // score word
     float* scratch = scratch_all + wave * (DMA_SLOTS * 64);
 
     const int nkb = a.d / BK;
@@ -986,15 +987,15 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
     const int c_chunk = (tid & 7) ^ ((tid >> 4) & 7);  // (row >> 1) & 7 == (t >> 4) & 7 for every round
     unsigned coff[4];
     const char* tile_ptr = nullptr;  // first row of the current column tile (uniform)
-    unsigned cb_bits = 0u;           // column side: bound of column show tid of the tile set last
+    u64 cb_key = 0ull;               // column side: bound key of column show tid of the tile set last
     auto set_tile = [&](int ct) {
         const ColRange& cr = ct >= rng0.tiles ? rng1 : rng0;
         const int64_t trow = (int64_t)(ct >= rng0.tiles ? ct - rng0.tiles : ct) * BN;
         const int last = (int)(cr.n - 1 - trow < BN ? cr.n - 1 - trow : BN);  // rows past the range's end repeat its last row
         if (COLSIDE) {
-            cb_bits = 0xFF800000u;  // +inf: nothing is accepted for rows past the range's end
+            cb_key = 0xFF800000FFFFFFFFull;  // +inf: nothing is accepted for rows past the range's end
             if (tid < BN && trow + tid < cr.n)
-                cb_bits = __hip_atomic_load(a.col_bound + cr.col_base + trow + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                cb_key = __hip_atomic_load(a.col_bound + cr.col_base + trow + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         {  // kept in scalar registers: the DMA instructions take a scalar base
             const uint64_t p = reinterpret_cast<uint64_t>(cr.z + trow * a.ld);
@@ -1087,7 +1088,10 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
         if (COLSIDE) {
             // the barrier that ended the previous tile also completed the loads of set_tile; the
             // epilogue that reads cbound and appends to the queue is many barriers away
-            if (tid < BN) cbound[tid] = ordered_to_f32(cb_bits);
+            if (tid < BN) {
+                cbound[tid] = ordered_to_f32((uint32_t)(cb_key >> 32));
+                cblo[tid] = (uint32_t)cb_key;
+            }
             unsigned queued_cols = *lcnt;
             if (queued_cols >= (unsigned)a.col_lds / 2) {  // uniform: drain the queue into the shows' buffers
                 if (queued_cols > (unsigned)a.col_lds) queued_cols = (unsigned)a.col_lds;
@@ -1244,9 +1248,12 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
                                 bits &= bits - 1u;
                                 const float v = scratch[slot * 64 + lane];
                                 ++slot;
-                                if (has) {
-                                    const unsigned rowg = (unsigned)col0 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * half;
-                                    const u64 key = make_key(v, (int)my_row);
+                                const int rowloc = 32 * j + (r & 3) + 8 * (r >> 2) + 4 * half;
+                                const u64 key = make_key(v, (int)my_row);
+                                // equal scores: only a key above the show's K-th key can enter its list
+                                const u64 bkey = ((u64)f32_to_ordered(cbound[rowloc]) << 32) | cblo[rowloc];
+                                if (has && key > bkey) {
+                                    const unsigned rowg = (unsigned)col0 + rowloc;
                                     const unsigned pos = atomicAdd(lcnt, 1u);
                                     if (pos < (unsigned)a.col_lds) {
                                         lkey[pos] = key;
@@ -1298,7 +1305,7 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
     }
 }
 
-__global__ __launch_bounds__(256) void bound_init_kernel(unsigned* __restrict__ bound, int64_t nq, unsigned v) {
+__global__ __launch_bounds__(256) void bound_init_kernel(u64* __restrict__ bound, int64_t nq, u64 v) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nq) bound[i] = v;
 }
@@ -1381,7 +1388,7 @@ constexpr int COLRED_ROWS = 4;
 
 __global__ __launch_bounds__(64 * COLRED_ROWS) void col_reduce_kernel(const unsigned* __restrict__ col_cnt,
                                                                       const u64* __restrict__ col_buf, int col_cap,
-                                                                      const unsigned* __restrict__ bound, int64_t n,
+                                                                      const u64* __restrict__ bound, int64_t n,
                                                                       int k, float min_similarity,
                                                                       u64* __restrict__ out, int64_t row0) {
     // shows row0 .. row0 + n - 1 of the buffers; list i of `out` belongs to show row0 + i
@@ -1393,13 +1400,13 @@ __global__ __launch_bounds__(64 * COLRED_ROWS) void col_reduce_kernel(const unsi
     u64* b = buf[wave];
     int m = (int)col_cnt[row0 + row];
     if (m > col_cap) m = col_cap;
-    const unsigned thr = bound[row0 + row];
+    const u64 thr = bound[row0 + row];  // K-th key of one of the show's own lists (or the empty-list sentinel)
     const u64* src = col_buf + (row0 + row) * col_cap;
     int packed = 0;
     for (int i0 = 0; i0 < m; i0 += 64) {
         const int i = i0 + lane;
         const u64 key = i < m ? src[i] : 0ull;
-        const bool keep = i < m && (unsigned)(key >> 32) >= thr;
+        const bool keep = i < m && key > thr;
         const u64 mask = __ballot(keep);
         if (keep) b[packed + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = key;
         packed += __builtin_popcountll(mask);
@@ -1775,22 +1782,29 @@ static int max_merge_slots(int k) { return k < 1 ? 0 : FIN_MAX_KEYS / k; }
 
 static int tiles_of(int64_t n) { return (int)((n + BN - 1) / BN); }
 
-// LDS queue of the column side: what is left of half a CU's LDS beside the lists and the tiles.
-// Returns the entries (0: does not fit) and the dynamic LDS bytes of the kernel.
-static int colside_queue(int k, int64_t d, size_t* lds_bytes) {
+// LDS of the sweeps with a column side: the lists (at most 34 entries per row, so that the queue
+// fits for every k <= 24), the tile's column bounds and a queue of (key, show) entries in what is
+// left of half a CU's LDS.  Returns the queue entries (0: does not fit), the dynamic LDS bytes of
+// the kernel and the list capacity to launch with.
+static int colside_queue(int k, int64_t d, size_t* lds_bytes, int* list_cap) {
     if (!topk_use_dma(d) || topk_list_global(k)) return 0;
-    const size_t base = topk_lds_bytes(k, d);
-    const size_t fixed = base + topk_static_lds_bytes(d) + BN * sizeof(float) + 16;
+    int cap = topk_cap(k, d);
+    if (cap > 34) cap = 34;
+    if (cap < k + 4) return 0;
+    const size_t base = (size_t)BM * cap * 8 + (size_t)BM * 8 + (size_t)BM * 4 + (size_t)4 * DMA_SLOTS * 64 * sizeof(float);
+    const size_t fixed = base + topk_static_lds_bytes(d) + BN * 8 + 16;  // score and column words of a tile's column bounds
     const size_t room = fixed < 80 * 1024 ? 80 * 1024 - fixed : 0;
     int q = (int)(room / 12) / 64 * 64;
     if (q > 1024) q = 1024;
     if (q < 128) return 0;
-    if (lds_bytes) *lds_bytes = base + BN * sizeof(float) + 16 + (size_t)q * 12;
+    if (lds_bytes) *lds_bytes = base + BN * 8 + 16 + (size_t)q * 12;
+    if (list_cap) *list_cap = cap;
     return q;
 }
 
-// workspace = [nq bound words, padded to 16 bytes][slot 0: nq x k keys][slot 1] ...
-static size_t ws_bound_bytes(int64_t nq) { return ((size_t)nq * 4 + 15) / 16 * 16; }
+// workspace = [nq bound keys, padded to 16 bytes][slot 0: nq x k keys][slot 1] ...
+static size_t ws_bound_bytes(int64_t nq) { return ((size_t)nq * 8 + 15) / 16 * 16; }
+static size_t ws_cnt_bytes(int64_t n) { return ((size_t)n * 4 + 15) / 16 * 16; }  // 32-bit counters
 static size_t ws_slot_bytes(int64_t nq, int k) { return (size_t)nq * (size_t)k * 8; }
 
 static int fill_blocks(BlockDesc* bd, const int32_t* off, const float* scale, int nb, int64_t d) {
@@ -1866,7 +1880,7 @@ int tvbf_topk_begin(int64_t nq, int k, float min_similarity, void* workspace, si
     if (nq == 0) return TVBF_OK;
     if (min_similarity < -FLT_MAX) min_similarity = -FLT_MAX;  // -inf marks masked columns
     hipLaunchKernelGGL(bound_init_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<unsigned*>(workspace), nq, f32_to_ordered(min_similarity));
+                       reinterpret_cast<u64*>(workspace), nq, sentinel_key(min_similarity));
     HIP_TRY(hipGetLastError());
     return TVBF_OK;
 }
@@ -1895,7 +1909,7 @@ static int validate_accumulate(const float* Zq, int64_t nq, int64_t q_row0, int6
 
 // column-side state: [overflow flag, 16 bytes][n_total counters, padded to 16 bytes][n_total x cap keys]
 static size_t cs_cnt_off() { return 16; }
-static size_t cs_buf_off(int64_t n_total) { return 16 + ws_bound_bytes(n_total); }
+static size_t cs_buf_off(int64_t n_total) { return 16 + ws_cnt_bytes(n_total); }
 
 static int check_colside(const tvbf_colside* cs) {
     if (!cs->col_bound || !cs->state || ((uintptr_t)cs->state & 15))
@@ -1926,13 +1940,13 @@ static int accumulate_impl(const float* Zq, int64_t nq, int64_t q_row0, int64_t 
 
     const int tiles = tiles_of(nA) + (nB ? tiles_of(nB) : 0);
     Plan p = make_plan(nq, tiles, d, k, device_cus(), max_slots);
-    int col_lds = 0;
+    int col_lds = 0, col_list_cap = 0;
     if (cs) {
         rc = check_colside(cs);
         if (rc) return rc;
         if (colA + nA > cs->n_total || colB + nB > cs->n_total)
             return fail(TVBF_E_BAD_SHAPE, "column side: column ranges must lie inside [0, n_total)");
-        col_lds = colside_queue(k, d, &p.lds_bytes);
+        col_lds = colside_queue(k, d, &p.lds_bytes, &col_list_cap);
         if (!col_lds)
             return fail(TVBF_E_BAD_SHAPE, "the column side needs d %% 64 == 0 and k <= 24");
         if (gate) return fail(TVBF_E_BAD_ARG, "a gated sweep has no column side");
@@ -1957,7 +1971,7 @@ static int accumulate_impl(const float* Zq, int64_t nq, int64_t q_row0, int64_t 
     a.rng[0] = ColRange{ZcA, nA, colA, tiles_of(nA)};
     a.rng[1] = ColRange{nB ? ZcB : ZcA, nB, colB, nB ? tiles_of(nB) : 0};
     char* ws = reinterpret_cast<char*>(workspace);
-    a.bound = reinterpret_cast<unsigned*>(ws);
+    a.bound = reinterpret_cast<u64*>(ws);
     a.partial = reinterpret_cast<u64*>(ws + ws_bound_bytes(nq) + (size_t)slot0 * ws_slot_bytes(nq, k));
     a.nq = nq;
     a.q_row0 = q_row0;
@@ -1973,12 +1987,13 @@ static int accumulate_impl(const float* Zq, int64_t nq, int64_t q_row0, int64_t 
     a.gate = gate;
     if (cs) {
         char* st = reinterpret_cast<char*>(cs->state);
-        a.col_bound = cs->col_bound;
+        a.col_bound = reinterpret_cast<const u64*>(cs->col_bound);
         a.overflow = reinterpret_cast<unsigned*>(st);
         a.col_cnt = reinterpret_cast<unsigned*>(st + cs_cnt_off());
         a.col_buf = reinterpret_cast<u64*>(st + cs_buf_off(cs->n_total));
         a.col_cap = cs->cap;
         a.col_lds = col_lds;
+        a.cap = col_list_cap;
     }
 #ifdef TVBF_DIAG_TIMELINE
     if (const char* e = getenv("TVBF_DIAG_BUF")) a.gram = reinterpret_cast<float*>(strtoull(e, nullptr, 0));
@@ -2020,6 +2035,94 @@ int tvbf_topk_accumulate_ex_f32(const float* Zq, int64_t nq, int64_t q_row0, int
                            workspace, workspace_bytes, slot0, max_slots, slots_used, colside, gate, stream);
 }
 
+// The symmetric sweep of a block of rows against itself inside an incremental sequence: the
+// own-columns sweep, the half sweep (column side into the caller's column-side state, at the
+// block's global rows) and the reduction of those buffers into one more list slot.
+int tvbf_topk_accumulate_sym_f32(const float* Zq, int64_t nq, int64_t q_row0, int64_t d, int64_t ld, int k,
+                                 float min_similarity, int exclude_self, void* workspace, size_t workspace_bytes,
+                                 int slot0, int max_slots, int* slots_used, const tvbf_colside* colside,
+                                 void* stream) {
+    if (!slots_used) return fail(TVBF_E_BAD_ARG, "slots_used must be non-null");
+    *slots_used = 0;
+    if (!colside) return fail(TVBF_E_BAD_ARG, "the symmetric sweep needs a column-side state");
+    int rc = validate_accumulate(Zq, nq, q_row0, d, ld, Zq, nq, q_row0, nullptr, 0, 0, k, min_similarity, workspace,
+                                 slot0, max_slots);
+    if (rc) return rc;
+    // only state, n_total and cap of the descriptor are used: the bounds are the workspace's own
+    if (!colside->state || ((uintptr_t)colside->state & 15) || colside->n_total < 1 || colside->cap < 1 ||
+        colside->cap > COL_CAP_MAX ||
+        colside->state_bytes < cs_buf_off(colside->n_total) + (size_t)colside->n_total * colside->cap * 8)
+        return fail(TVBF_E_BAD_SHAPE, "column side: bad state");
+    if (q_row0 + nq > colside->n_total) return fail(TVBF_E_BAD_SHAPE, "column side: rows must lie inside [0, n_total)");
+    if (nq == 0) return TVBF_OK;
+    if (min_similarity < -FLT_MAX) min_similarity = -FLT_MAX;
+    size_t lds_half = 0;
+    int half_cap = 0;
+    const int col_lds = colside_queue(k, d, &lds_half, &half_cap);
+    const int row_blocks = (int)((nq + BM - 1) / BM);
+    int shards = row_blocks / 8 < 48 ? row_blocks / 8 : 48;
+    if (const char* e = getenv("TVBF_SYM_SHARDS")) shards = atoi(e);
+    if (shards > row_blocks) shards = row_blocks;
+    if (!col_lds || shards < 2)
+        return fail(TVBF_E_BAD_SHAPE, "the symmetric sweep needs d %% 64 == 0, k <= 24 and at least 16 row blocks");
+    const int cus = device_cus();
+    const int sh_blocks = (row_blocks + shards - 1) / shards;
+    int budget = max_slots - 1;  // one slot is the reduced column side
+    if (budget < 2) return fail(TVBF_E_BAD_ARG, "the symmetric sweep needs at least 3 slots");
+    const Plan pd = make_plan(nq, sh_blocks, d, k, cus, budget / 2 > 4 ? 4 : budget / 2);
+    const Plan ph = make_plan(nq, (shards - 1) * sh_blocks / 2 + 1, d, k, cus, budget - pd.splits);
+    const int total = pd.splits + ph.splits + 1;
+    const size_t need = ws_bound_bytes(nq) + (size_t)(slot0 + total) * ws_slot_bytes(nq, k);
+    if (workspace_bytes < need) return fail(TVBF_E_BAD_SHAPE, "workspace must be >= %zu bytes", need);
+
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = reinterpret_cast<char*>(workspace);
+    char* cst = reinterpret_cast<char*>(colside->state);
+    TopkArgs a;
+    memset(&a, 0, sizeof(a));
+    a.zq = Zq;
+    a.rng[0] = ColRange{Zq, nq, q_row0, tiles_of(nq)};
+    a.rng[1] = ColRange{Zq, 0, 0, 0};
+    a.bound = reinterpret_cast<u64*>(ws);
+    a.nq = nq;
+    a.q_row0 = q_row0;
+    a.ld = ld;
+    a.d = (int)d;
+    a.k = k;
+    a.cap = topk_cap(k, d);
+    a.row_blocks = row_blocks;
+    a.col_tiles = tiles_of(nq);
+    a.min_similarity = min_similarity;
+    a.exclude_self = exclude_self;
+    a.shards = shards;
+    a.col_bound = a.bound - q_row0;  // indexed by global row; only this block's rows are ever read
+    a.overflow = reinterpret_cast<unsigned*>(cst);
+    a.col_cnt = reinterpret_cast<unsigned*>(cst + cs_cnt_off());
+    a.col_buf = reinterpret_cast<u64*>(cst + cs_buf_off(colside->n_total));
+    a.col_cap = colside->cap;
+    a.col_lds = col_lds;
+    u64* lists = reinterpret_cast<u64*>(ws + ws_bound_bytes(nq)) + (size_t)slot0 * nq * k;
+    const void* k_diag = reinterpret_cast<const void*>(cosine_topk_dma_kernel<false, SYM_DIAG>);
+    const void* k_half = reinterpret_cast<const void*>(cosine_topk_dma_kernel<false, SYM_HALF>);
+    HIP_TRY(hipFuncSetAttribute(k_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pd.lds_bytes));
+    HIP_TRY(hipFuncSetAttribute(k_half, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_half));
+    a.partial = lists;
+    a.splits = pd.splits;
+    hipLaunchKernelGGL((cosine_topk_dma_kernel<false, SYM_DIAG>), dim3((unsigned)(row_blocks * pd.splits)),
+                       dim3(TOPK_THREADS), pd.lds_bytes, st, a);
+    a.partial = lists + (size_t)pd.splits * nq * k;
+    a.splits = ph.splits;
+    a.cap = half_cap;
+    hipLaunchKernelGGL((cosine_topk_dma_kernel<false, SYM_HALF>), dim3((unsigned)(row_blocks * ph.splits)),
+                       dim3(TOPK_THREADS), lds_half, st, a);
+    hipLaunchKernelGGL(col_reduce_kernel, dim3((unsigned)((nq + COLRED_ROWS - 1) / COLRED_ROWS)), dim3(64 * COLRED_ROWS),
+                       0, st, a.col_cnt, a.col_buf, a.col_cap, a.col_bound, nq, k, min_similarity,
+                       lists + (size_t)(pd.splits + ph.splits) * nq * k, q_row0);
+    HIP_TRY(hipGetLastError());
+    *slots_used = total;
+    return TVBF_OK;
+}
+
 size_t tvbf_topk_colside_bytes(int64_t n_total, int cap) {
     if (n_total < 1 || cap < 1 || cap > COL_CAP_MAX) return 0;
     return cs_buf_off(n_total) + (size_t)n_total * cap * 8;
@@ -2049,7 +2152,7 @@ int tvbf_topk_colside_reduce(const tvbf_colside* cs, int64_t row0, int64_t rows,
     hipLaunchKernelGGL(col_reduce_kernel, dim3((unsigned)((rows + COLRED_ROWS - 1) / COLRED_ROWS)),
                        dim3(64 * COLRED_ROWS), 0, (hipStream_t)stream,
                        reinterpret_cast<const unsigned*>(st + cs_cnt_off()),
-                       reinterpret_cast<const u64*>(st + cs_buf_off(cs->n_total)), (int)cs->cap, cs->col_bound, rows, k,
+                       reinterpret_cast<const u64*>(st + cs_buf_off(cs->n_total)), (int)cs->cap, reinterpret_cast<const u64*>(cs->col_bound), rows, k,
                        min_similarity, reinterpret_cast<u64*>(lists), row0);
     HIP_TRY(hipGetLastError());
     return TVBF_OK;
@@ -2140,7 +2243,7 @@ struct SymPlan {
     bool ok;
     int row_blocks, shards;
     int s_diag, s_half, s_full;  // column splits (= list slots) of the three sweeps
-    int col_cap, col_lds;
+    int col_cap, col_lds, half_cap;
     size_t lds_diag, lds_half;
     size_t off_cnt, off_flag, off_buf, bytes;
 };
@@ -2166,7 +2269,7 @@ static SymPlan make_sym_plan(int64_t n, int64_t d, int k) {
     sp.s_full = full.splits;
     if (sp.s_diag + sp.s_half + 1 > slots || sp.s_full > slots) return sp;
     sp.lds_diag = full.lds_bytes;
-    sp.col_lds = colside_queue(k, d, &sp.lds_half);
+    sp.col_lds = colside_queue(k, d, &sp.lds_half, &sp.half_cap);
     if (!sp.col_lds) return sp;
     sp.col_cap = 1024;
     if (const char* e = getenv("TVBF_SYM_COL_CAP")) sp.col_cap = atoi(e);  // tuning / test aid
@@ -2174,7 +2277,7 @@ static SymPlan make_sym_plan(int64_t n, int64_t d, int k) {
     if (sp.col_cap > COL_CAP_MAX) sp.col_cap = COL_CAP_MAX;
     const int lists = sp.s_diag + sp.s_half + 1 + sp.s_full;
     sp.off_cnt = ws_bound_bytes(n) + (size_t)lists * ws_slot_bytes(n, k);
-    sp.off_flag = sp.off_cnt + ws_bound_bytes(n);
+    sp.off_flag = sp.off_cnt + ws_cnt_bytes(n);
     sp.off_buf = sp.off_flag + 16;
     sp.bytes = sp.off_buf + (size_t)n * sp.col_cap * 8;
     sp.ok = true;
@@ -2201,7 +2304,7 @@ int tvbf_cosine_topk_sym_f32(const float* Z, int64_t n, int64_t d, int64_t ld, i
     if (min_similarity < -FLT_MAX) min_similarity = -FLT_MAX;
     hipStream_t st = (hipStream_t)stream;
     char* ws = reinterpret_cast<char*>(workspace);
-    unsigned* bound = reinterpret_cast<unsigned*>(ws);
+    u64* bound = reinterpret_cast<u64*>(ws);
     unsigned* col_cnt = reinterpret_cast<unsigned*>(ws + sp.off_cnt);
     unsigned* flag = reinterpret_cast<unsigned*>(ws + sp.off_flag);
     u64* col_buf = reinterpret_cast<u64*>(ws + sp.off_buf);
@@ -2209,7 +2312,7 @@ int tvbf_cosine_topk_sym_f32(const float* Z, int64_t n, int64_t d, int64_t ld, i
     const size_t slot_keys = (size_t)n * k;
 
     hipLaunchKernelGGL(bound_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, bound, n,
-                       f32_to_ordered(min_similarity));
+                       sentinel_key(min_similarity));
     // counters and the flag behind them are one stretch of the workspace
     const int64_t words = (int64_t)((sp.off_buf - sp.off_cnt) / 4);
     hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, col_cnt, words, 0u);
@@ -2251,6 +2354,7 @@ int tvbf_cosine_topk_sym_f32(const float* Z, int64_t n, int64_t d, int64_t ld, i
                        dim3(TOPK_THREADS), sp.lds_diag, st, a);
     a.partial = lists + (size_t)sp.s_diag * slot_keys;
     a.splits = sp.s_half;
+    a.cap = sp.half_cap;
     hipLaunchKernelGGL((cosine_topk_dma_kernel<false, SYM_HALF>), dim3((unsigned)(sp.row_blocks * sp.s_half)),
                        dim3(TOPK_THREADS), sp.lds_half, st, a);
     hipLaunchKernelGGL(col_reduce_kernel, dim3((unsigned)((n + COLRED_ROWS - 1) / COLRED_ROWS)), dim3(64 * COLRED_ROWS),
@@ -2260,6 +2364,7 @@ int tvbf_cosine_topk_sym_f32(const float* Z, int64_t n, int64_t d, int64_t ld, i
     const int first_full = sp.s_diag + sp.s_half + 1;
     a.partial = lists + (size_t)first_full * slot_keys;
     a.splits = sp.s_full;
+    a.cap = topk_cap(k, d);
     a.gate = flag;
     hipLaunchKernelGGL((cosine_topk_dma_kernel<false, SYM_OFF>), dim3((unsigned)(sp.row_blocks * sp.s_full)),
                        dim3(TOPK_THREADS), sp.lds_diag, st, a);

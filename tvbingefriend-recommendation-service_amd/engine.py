@@ -493,13 +493,33 @@ class TopkSession:
         return t.data_ptr(), n, int(col0), t
 
     def bounds(self) -> torch.Tensor:
-        """The per-row lower bounds of the K-th scores (ordered-float words, as an int32 view of
-        the start of the workspace): what a shard publishes for the column side of its peers."""
-        return self.workspace.view(torch.int32)[: self.nq]
+        """The per-row lower bounds of the K-th keys (64-bit keys at the start of the workspace):
+        what a shard publishes for the column side of its peers."""
+        return self.workspace[: self.nq]
+
+    def accumulate_own_symmetric(self, side: "ColumnSide", max_slots: int = 16) -> int:
+        """The block of these rows against their own columns (z_q is both), every pair once; the
+        column side goes through ``side`` at the rows' global indices.  Raises when the shape is
+        not taken (row length not a multiple of 64, k > 24, fewer than 2048 rows)."""
+        import ctypes
+
+        if self.nq == 0:
+            return 0
+        budget = min(max_slots, self.slots - self.used)
+        used = ctypes.c_int(0)
+        st = native.ColSide(None, side.state.data_ptr(), side.bytes, side.n_total, side.cap)
+        with torch.cuda.device(self.dev):
+            rc = self.lib.tvbf_topk_accumulate_sym_f32(
+                self.z_q.data_ptr(), self.nq, self.q_row0, self.ld, self.ld, self.k, self.min_similarity,
+                1 if self.exclude_self else 0, self.workspace.data_ptr(), self.ws_bytes, self.used, budget,
+                ctypes.byref(used), ctypes.byref(st), _stream_ptr())
+        native.check(rc, "tvbf_topk_accumulate_sym_f32")
+        self.used += used.value
+        return used.value
 
     def slot_lists(self) -> torch.Tensor:
         """The partial lists written so far: (slots used, nq, k) int64 keys (a view of the workspace)."""
-        first = ((self.nq * 4 + 15) // 16 * 16) // 8
+        first = ((self.nq * 8 + 15) // 16 * 16) // 8
         return self.workspace[first : first + self.used * self.nq * self.k].view(self.used, self.nq, self.k)
 
     def accumulate(self, range_a, range_b=None, max_slots: int = 16, *, colside=None, gate=None) -> int:
@@ -569,7 +589,7 @@ class ColumnSide:
     catalogue a counter and a buffer of ``cap`` candidates (score, global row of the query side),
     behind one overflow flag."""
 
-    def __init__(self, n_total: int, device, cap: int = 512):
+    def __init__(self, n_total: int, device, cap: int = 1024):
         self.lib = native.load()
         self.n_total, self.cap, self.dev = int(n_total), int(cap), torch.device(device)
         self.bytes = int(self.lib.tvbf_topk_colside_bytes(self.n_total, self.cap))
@@ -590,9 +610,9 @@ class ColumnSide:
         return self.state.view(torch.int32)[:1]
 
     def struct(self, col_bound: torch.Tensor):
-        _require_cuda(col_bound, "col_bound", dtype=torch.int32)
+        _require_cuda(col_bound, "col_bound", dtype=torch.int64)
         if col_bound.dim() != 1 or col_bound.numel() < self.n_total or not col_bound.is_contiguous():
-            raise ValueError("col_bound must hold n_total contiguous words")
+            raise ValueError("col_bound must hold n_total contiguous keys")
         self._struct = native.ColSide(col_bound.data_ptr(), self.state.data_ptr(), self.bytes, self.n_total, self.cap)
         self._keep = col_bound
         return self._struct

@@ -37,6 +37,7 @@ SYMBOLS = (
     "tvbf_topk_colside_bytes",
     "tvbf_topk_colside_begin",
     "tvbf_topk_accumulate_ex_f32",
+    "tvbf_topk_accumulate_sym_f32",
     "tvbf_topk_colside_reduce",
     "tvbf_topk_finish_ex",
     "tvbf_query_workspace_bytes",
@@ -154,6 +155,9 @@ def load() -> ctypes.CDLL:
     lib.tvbf_topk_accumulate_ex_f32.argtypes = [vp, i64, i64, i64, i64, vp, i64, i64, vp, i64, i64, c.c_int, f32,
                                                 c.c_int, vp, sz, c.c_int, c.c_int, c.POINTER(c.c_int),
                                                 c.POINTER(ColSide), vp, vp]
+    lib.tvbf_topk_accumulate_sym_f32.restype = c.c_int
+    lib.tvbf_topk_accumulate_sym_f32.argtypes = [vp, i64, i64, i64, i64, c.c_int, f32, c.c_int, vp, sz, c.c_int,
+                                                 c.c_int, c.POINTER(c.c_int), c.POINTER(ColSide), vp]
     lib.tvbf_topk_colside_reduce.restype = c.c_int
     lib.tvbf_topk_colside_reduce.argtypes = [c.POINTER(ColSide), i64, i64, c.c_int, f32, vp, vp]
     lib.tvbf_topk_finish_ex.restype = c.c_int

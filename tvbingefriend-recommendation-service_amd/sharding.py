@@ -124,7 +124,7 @@ def sharded_topk(x_shard: torch.Tensor, offsets, scales, shard: Shard, k: int, m
 # ---------------------------------------------------------------------------
 # Symmetric sharded sweep: of two shards only one computes the block between them.
 # ---------------------------------------------------------------------------
-PAD_BOUND = -8388608  # int32 view of the ordered-float word of +inf: a padding row accepts nothing
+PAD_BOUND = 0xFF800000FFFFFFFF - (1 << 64)  # int64 view of the largest key (+inf): a padding row accepts nothing
 
 
 def half_peers(world: int, rank: int) -> list[int]:
@@ -176,7 +176,7 @@ class SymmetricShardJob:
     collectives (sharded_topk_symmetric does; a test can drive several simulated ranks in lockstep):
 
         phase_own()            own rows x own columns (overlaps the all-gather of Z)
-        own_bounds()           -> (per_rank,) int32 words to all-gather
+        own_bounds()           -> (per_rank,) int64 keys to all-gather
         phase_half(z_all, b)   own rows x the columns of half_pieces(), rows AND columns fed; the
                                upper partner of an even world also sweeps its rows [h0, rows)
                                against its partner's columns
@@ -185,8 +185,8 @@ class SymmetricShardJob:
         finish(z_all, recv, flag) gated plain re-run + merge of own lists and the received ones
     """
 
-    def __init__(self, z_shard: torch.Tensor, shard: Shard, k: int, min_similarity: float, *, col_cap: int = 512,
-                 slots: int = 64, workspace: torch.Tensor | None = None, colside=None):
+    def __init__(self, z_shard: torch.Tensor, shard: Shard, k: int, min_similarity: float, *, col_cap: int = 1024,
+                 slots: int = 96, workspace: torch.Tensor | None = None, colside=None):
         from . import engine
 
         self.engine, self.shard, self.k, self.min_similarity = engine, shard, int(k), float(min_similarity)
@@ -209,10 +209,13 @@ class SymmetricShardJob:
 
     def phase_own(self):
         own, _, _ = column_pieces(self.shard)
-        self.session.accumulate((self.z_shard, own[1], own[0]))
+        if self.shard.rows >= 2048:   # large enough for the symmetric sweep inside the block
+            self.session.accumulate_own_symmetric(self.side)
+        else:
+            self.session.accumulate((self.z_shard, own[1], own[0]))
 
     def own_bounds(self) -> torch.Tensor:
-        b = torch.full((self.shard.per_rank,), PAD_BOUND, dtype=torch.int32, device=self.dev)
+        b = torch.full((self.shard.per_rank,), PAD_BOUND, dtype=torch.int64, device=self.dev)
         if self.shard.rows:
             b[: self.shard.rows] = self.session.bounds()
         return b
