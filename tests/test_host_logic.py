@@ -297,3 +297,177 @@ def test_columnar_table_equals_record_dicts(pkg, tmp_path):
     assert sink.store_similarity_table(table) == len(flat)
     st = sink.get_similarity_stats()
     assert st["total_records"] == len(flat) and st["unique_shows"] == len(recs)
+
+
+# ------------------------------------------ symmetric sharded sweep (gloo) ----
+
+def _f32_ordered(x):
+    u = np.asarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    return np.where(u & 0x80000000, u ^ 0xFFFFFFFF, u | 0x80000000)
+
+
+def _ordered_f32(m):
+    m = np.asarray(m, dtype=np.uint64)
+    u = np.where(m & 0x80000000, m ^ 0x80000000, m ^ 0xFFFFFFFF).astype(np.uint32)
+    return u.view(np.float32)
+
+
+def _sym_worker(rank, world, port, n, k, min_sim, ret):
+    """One gloo rank of sharded_topk_symmetric: the real partition logic and collectives around a
+    CPU stand-in for the device job (float64 products, keys in the device format)."""
+    import torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    import tvbf_amd  # noqa: F401
+    from tvbingefriend_recommendation_service_amd import engine, sharding
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g, t, p, ty, la = hybrid_like_blocks(n, seed=11, d_genre=12, d_text=40)
+        x = np.hstack([g, t, p, ty, la]).astype(np.float32)
+        offsets, weights = [0, 12, 52, 84], [0.4, 0.5, 0.1]
+        scales = [float(np.sqrt(w)) for w in weights]
+        sh = sharding.shard_bounds(n, world, rank)
+        xs = np.zeros((sh.per_rank, x.shape[1]), np.float32)
+        xs[: sh.rows] = x[sh.row0 : sh.row0 + sh.rows]
+
+        def normalize_fn(xt, off, sc):
+            xx = xt.numpy().astype(np.float64)
+            z = np.hstack([s * so.l2_normalize_rows(xx[:, off[b] : off[b + 1]]) for b, s in enumerate(sc)])
+            return torch.from_numpy(np.ascontiguousarray(z))
+
+        class OracleJob:
+            """CPU stand-in with the phases of sharding.SymmetricShardJob."""
+
+            def __init__(self, z_shard, shard, kk, ms):
+                self.sh, self.k, self.ms = shard, kk, ms
+                self.zq = z_shard.numpy()[: shard.rows]
+                self.row_scores = [[] for _ in range(shard.rows)]   # per own row: (score f32, global col)
+                self.col_scores = {}                                # global row -> [(score f32, global col)]
+                self.entries = 0                                    # score-matrix entries computed here
+
+            def _sweep(self, r_lo, zc, col0, both):
+                h = (self.zq[r_lo:] @ zc.T).astype(np.float32)
+                self.entries += h.size
+                for i in range(h.shape[0]):
+                    gi = self.sh.row0 + r_lo + i
+                    for j in range(h.shape[1]):
+                        self.row_scores[r_lo + i].append((h[i, j], col0 + j))
+                        if both:
+                            self.col_scores.setdefault(col0 + j, []).append((h[i, j], gi))
+
+            def phase_own(self):
+                self._sweep(0, self.zq, self.sh.row0, both=False)
+
+            def own_bounds(self):
+                return torch.zeros((self.sh.per_rank,), dtype=torch.int64)
+
+            def phase_half(self, z_all, bounds_all):
+                assert bounds_all.shape == (self.sh.padded_total,)
+                za = z_all.numpy()
+                for first, rows in sharding.half_pieces(self.sh):
+                    if rows:
+                        self._sweep(0, za[first : first + rows], first, both=True)
+                pt = sharding.partner(self.sh.world, self.sh.rank)
+                if pt is not None and self.sh.rank >= self.sh.world // 2:
+                    h0 = sharding.partner_split(self.sh, self.sh.rank)
+                    c0 = min(pt * self.sh.per_rank, self.sh.n)
+                    cols = min((pt + 1) * self.sh.per_rank, self.sh.n) - c0
+                    if self.sh.rows - h0 > 0 and cols > 0:
+                        self._sweep(h0, za[c0 : c0 + cols], c0, both=True)
+
+            @staticmethod
+            def _keys(pairs):
+                s = np.array([p_[0] for p_ in pairs], dtype=np.float32)
+                c = np.array([p_[1] for p_ in pairs], dtype=np.uint64)
+                return (_f32_ordered(s) << np.uint64(32)) | (np.uint64(0xFFFFFFFF) - c)
+
+            def lists_for_peers(self, bounds_all):
+                send = np.zeros((self.sh.world, self.sh.per_rank, self.k), dtype=np.uint64)
+                for grow, pairs in self.col_scores.items():
+                    keys = np.sort(self._keys(pairs))[::-1][: self.k]
+                    send[grow // self.sh.per_rank, grow % self.sh.per_rank, : len(keys)] = keys
+                return torch.from_numpy(send.view(np.int64))
+
+            @property
+            def flag(self):
+                return torch.zeros((1,), dtype=torch.int32)
+
+            def finish(self, z_all, recv, flag):
+                assert int(flag.item()) == 0
+                rk = recv.numpy().view(np.uint64)
+                idx = -np.ones((self.sh.rows, self.k), np.int32)
+                score = np.zeros((self.sh.rows, self.k), np.float32)
+                count = np.zeros((self.sh.rows,), np.int32)
+                for i in range(self.sh.rows):
+                    keys = self._keys(self.row_scores[i])
+                    theirs = rk[:, i, :].ravel()
+                    keys = np.concatenate([keys, theirs[(theirs & np.uint64(0xFFFFFFFF)) != 0]])
+                    cols = (np.uint64(0xFFFFFFFF) - (keys & np.uint64(0xFFFFFFFF))).astype(np.int64)
+                    assert len(set(cols.tolist())) == len(cols), "a pair reached this row twice"
+                    keys = keys[cols != self.sh.row0 + i]
+                    keys = np.sort(keys)[::-1]
+                    sc = _ordered_f32(keys >> np.uint64(32))
+                    keep = sc >= self.ms
+                    keys, sc = keys[keep][: self.k], sc[keep][: self.k]
+                    c = len(keys)
+                    idx[i, :c] = (np.uint64(0xFFFFFFFF) - (keys & np.uint64(0xFFFFFFFF))).astype(np.int32)
+                    score[i, :c] = sc
+                    count[i] = c
+                return engine.TopK(torch.from_numpy(idx), torch.from_numpy(score), torch.from_numpy(count))
+
+        holder = {}
+
+        def job_fn(*a):
+            holder["job"] = OracleJob(*a)
+            return holder["job"]
+
+        top, z_all = sharding.sharded_topk_symmetric(torch.from_numpy(xs), offsets, scales, sh, k, min_sim,
+                                                     normalize_fn=normalize_fn, job_fn=job_fn)
+        entries = torch.tensor([holder["job"].entries], dtype=torch.int64)
+        dist.all_reduce(entries)
+        idx = sharding.gather_lists(top.idx, sh)
+        score = sharding.gather_lists(top.score, sh)
+        count = sharding.gather_lists(top.count, sh)
+        if rank == 0:
+            ret["idx"], ret["score"], ret["count"] = idx.numpy(), score.numpy(), count.numpy()
+            ret["entries"] = int(entries.item())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,world", [(101, 2), (64, 2), (130, 3), (150, 4)])
+def test_sharded_topk_symmetric_gloo(pkg, n, world):
+    """Real ranks over gloo: the partition (half peers, split partner block), the all-gathers, the
+    all-to-all of lists and the flag reduction hand every pair of shows to exactly one rank, and
+    the merged lists equal the single-process result."""
+    import torch.multiprocessing as mp
+
+    from tvbingefriend_recommendation_service_amd import sharding
+
+    k, min_sim = 7, 0.1
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_sym_worker, args=(r, world, port, n, k, min_sim, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    rows = [sharding.shard_bounds(n, world, r).rows for r in range(world)]
+    # own blocks in full, every block between two shards once
+    assert ret["entries"] == sum(a * a for a in rows) + sum(rows[a] * rows[b] for a in range(world) for b in range(a))
+    g, t, p_, ty, la = hybrid_like_blocks(n, seed=11, d_genre=12, d_text=40)
+    x = np.hstack([g, t, p_, ty, la]).astype(np.float32).astype(np.float64)
+    z = np.hstack([np.sqrt(w) * so.l2_normalize_rows(x[:, a:b])
+                   for w, a, b in ((0.4, 0, 12), (0.5, 12, 52), (0.1, 52, 84))])
+    from parity import check_topk_against_scores
+
+    check_topk_against_scores(z @ z.T, 0, k, min_sim, ret["idx"], ret["score"], ret["count"], tol=1e-6,
+                              what=f"gloo symmetric shards n={n} world={world}", check_tie_order=False)
