@@ -72,9 +72,11 @@ def test_symmetric_equals_plain_hybrid(pkg, device, monkeypatch, n, shards):
 
 
 @pytest.mark.parametrize("n,d,k", [(1300, 64, 24), (3000, 128, 20), (1025, 192, 1)])
-def test_symmetric_dense_against_oracle(pkg, device, n, d, k):
+def test_symmetric_dense_against_oracle(pkg, device, monkeypatch, n, d, k):
     """No min_similarity cut, negative scores in the lists: against the float64 oracle and the plain sweep."""
     import torch
+
+    monkeypatch.setenv("TVBF_SYM_SHARDS", "3")  # fewer than 2048 shows: not taken by default
 
     from tvbingefriend_recommendation_service_amd import engine
 
@@ -89,8 +91,10 @@ def test_symmetric_dense_against_oracle(pkg, device, n, d, k):
                               what=f"symmetric dense {n}x{d} k={k}")
 
 
-def test_symmetric_keeps_self_when_asked(pkg, device):
+def test_symmetric_keeps_self_when_asked(pkg, device, monkeypatch):
     import torch
+
+    monkeypatch.setenv("TVBF_SYM_SHARDS", "4")
 
     from tvbingefriend_recommendation_service_amd import engine
 
@@ -112,6 +116,7 @@ def test_symmetric_overflow_recomputes_plainly(pkg, device, monkeypatch):
 
     z, _, _ = _z_hybrid(device, 1700, seed=31)
     plain = engine.cosine_topk(z, 20, 0.1)
+    monkeypatch.setenv("TVBF_SYM_SHARDS", "2")
     monkeypatch.setenv("TVBF_SYM_COL_CAP", "2")
     sym = _sym(z, 20, 0.1, expect_overflow=True)
     torch.cuda.synchronize()
@@ -144,7 +149,8 @@ def test_symmetric_shape_limits(pkg, device):
     assert engine.symmetric_workspace_bytes(100_000, 1024, 20) > 0
     assert engine.symmetric_workspace_bytes(100_000, 1024 + 32, 20) == 0  # row length must be a multiple of 64
     assert engine.symmetric_workspace_bytes(100_000, 1024, 50) == 0       # lists and queue would not fit LDS
-    assert engine.symmetric_workspace_bytes(100, 64, 5) == 0              # a single row block
+    assert engine.symmetric_workspace_bytes(1900, 64, 5) == 0             # fewer than 16 blocks of 128 shows
+    assert engine.symmetric_workspace_bytes(2048, 64, 5) > 0
     z = torch.zeros((100, 64), device=device)
     with pytest.raises(ValueError):
         engine.cosine_topk_symmetric(z, 5, 0.0)

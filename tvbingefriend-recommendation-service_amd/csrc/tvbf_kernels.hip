@@ -152,6 +152,8 @@ struct ColRange {
     int tiles;         // ceil(n / BN)
 };
 
+constexpr int MAX_SHARDS = 64;
+
 struct TopkArgs {
     const float* zq;
     ColRange rng[2];
@@ -172,6 +174,15 @@ struct TopkArgs {
     // symmetric sweep (query rows and columns are the same matrix, given whole as rng[0]): the row
     // blocks form `shards` groups of (nearly) equal size; the kernel derives each group's column ranges
     int shards;
+    // work of the LDS-DMA kernels: the column tiles of all row blocks form one line (row block
+    // after row block; a row block of shard v has sh_tiles[v] of them), cut into `items` equal
+    // stretches, one per workgroup.  A workgroup walks through the row blocks its stretch touches;
+    // the stretches inside one row block are numbered 0, 1, ... and write list slot 0, 1, ...
+    int items, n_sh;
+    int64_t total_tiles;
+    int sh_block0[MAX_SHARDS];       // first row block of shard v
+    int sh_tiles[MAX_SHARDS];        // column tiles of each of its row blocks
+    int64_t sh_prefix[MAX_SHARDS + 1];  // tiles of all row blocks before shard v
     // column side of a tile: a score that reaches the bound of its COLUMN's show is appended to
     // that show's buffer -- the pair is then never computed with the roles swapped
     const u64* col_bound;       // [shows] lower bounds of the K-th keys, by global row
@@ -876,6 +887,33 @@ constexpr int DMA_SLOTS = 8;  // scores a lane can queue per collect pass
 // candidates their own sweep would have found.
 enum { SYM_OFF = 0, SYM_DIAG = 1, SYM_HALF = 2 };
 
+// Rows [a0, a1) and [b0, b1) of the matrix that shard v sweeps as columns.  Shard s = row blocks
+// [s * RB / V, (s + 1) * RB / V): sizes differ by one block at most.
+struct ShardSpans {
+    int64_t a0, a1, b0, b1;
+};
+__host__ __device__ static inline ShardSpans shard_spans(int sym, int v, int V, int RB, int64_t n_all) {
+    auto row_of = [=](int shard) {
+        const int64_t r = (int64_t)(((int64_t)shard * RB) / V) * BM;
+        return r < n_all ? r : n_all;
+    };
+    ShardSpans sp{0, 0, 0, 0};
+    if (sym == SYM_DIAG) {
+        sp.a0 = row_of(v), sp.a1 = row_of(v + 1);
+        return sp;
+    }
+    int h = (V - 1) / 2;
+    if (!(V & 1) && v < V / 2) ++h;  // even count: the pair at distance V / 2 goes to the lower shard
+    const int s0 = v + 1 >= V ? 0 : v + 1;
+    if (s0 + h <= V) {
+        sp.a0 = row_of(s0), sp.a1 = row_of(s0 + h);
+    } else {
+        sp.a0 = row_of(s0), sp.a1 = row_of(V);
+        sp.b0 = 0, sp.b1 = row_of(s0 + h - V);
+    }
+    return sp;
+}
+
 __device__ static inline void col_append(const TopkArgs& a, unsigned rowg, u64 key) {
     const unsigned p = atomicAdd(a.col_cnt + rowg, 1u);
     if (p < (unsigned)a.col_cap)
@@ -911,50 +949,56 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
     const int half = lane >> 5;
     const int lrow = wave * 32 + (lane & 31);
 
-    const int rb = blockIdx.x % a.row_blocks;
-    const int split = blockIdx.x / a.row_blocks;
+    float* scratch = scratch_all + wave * (DMA_SLOTS * 64);
+    const int nkb = a.d / BK;
+    // ---- column tile: thread t moves, in round i, the 16 bytes that land at LDS byte
+    // i*4096 + t*16 of the buffer = row i*32 + t/8, slot t%8; the slot holds chunk slot ^ swizzle ----
+    const int c_chunk = (tid & 7) ^ ((tid >> 4) & 7);  // (row >> 1) & 7 == (t >> 4) & 7 for every round
+    // ---- fragment reads of the column tile: row (lane & 31) + 32 j, chunk 2 t + half ----
+    unsigned foff[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+        foff[t] = (unsigned)((lane & 31) * 128 + (((2 * t + half) ^ (((lane & 31) >> 1) & 7)) << 4));
+    f32x16 acc[NJ];  // zero between tiles: the epilogue clears what it has read
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    if (COLSIDE && tid == 0) *lcnt = 0u;
+
+    // ---- this workgroup's stretch of the line of column tiles ----
+    int64_t x_pos = (a.total_tiles * (int64_t)blockIdx.x) / a.items;
+    const int64_t x_end = (a.total_tiles * ((int64_t)blockIdx.x + 1)) / a.items;
+    bool first_segment = true;
+#pragma nounroll
+    while (x_pos < x_end) {  // one segment: a run of column tiles of one row block
+    int v = 0;
+    while (v + 1 < a.n_sh && a.sh_prefix[v + 1] <= x_pos) ++v;
+    const int64_t rel = x_pos - a.sh_prefix[v];
+    const int tiles_v = a.sh_tiles[v];
+    const int rb = a.sh_block0[v] + (int)(rel / tiles_v);
+    const int tile_begin = (int)(rel % tiles_v);
+    const int tile_end = x_pos + (tiles_v - tile_begin) > x_end ? tile_begin + (int)(x_end - x_pos) : tiles_v;
+    // slot: the stretches that cut this row block's tiles are numbered from the one holding its first tile
+    const int split = (int)blockIdx.x - (int)((((x_pos - tile_begin) + 1) * a.items - 1) / a.total_tiles);
+    x_pos += tile_end - tile_begin;
     ColRange rng0 = a.rng[0], rng1 = a.rng[1];
-    int col_tiles = a.col_tiles;
     if (SYM != SYM_OFF) {
-        // shard s = row blocks [s * row_blocks / shards, (s + 1) * row_blocks / shards): sizes differ by one block at most
-        const int64_t n_all = a.rng[0].n, base0 = a.rng[0].col_base;
+        const ShardSpans sp = shard_spans(SYM, v, a.shards, a.row_blocks, a.rng[0].n);
         const float* z_all = a.rng[0].z;
-        const int64_t ld = a.ld;
-        const int RB = a.row_blocks, V = a.shards;
-        auto span = [=](int first, int count) {  // shards [first, first + count), count >= 0, no wrap
-            const int64_t r0 = (int64_t)(((int64_t)first * RB) / V) * BM;
-            int64_t r1 = (int64_t)(((int64_t)(first + count) * RB) / V) * BM;
-            if (r1 > n_all) r1 = n_all;
-            return ColRange{z_all + r0 * ld, r1 - r0, base0 + r0, (int)((r1 - r0 + BN - 1) / BN)};
-        };
-        const int v = (int)((((int64_t)rb + 1) * V - 1) / RB);
-        if (SYM == SYM_DIAG) {
-            rng0 = span(v, 1);
-            rng1 = span(0, 0);
-        } else {
-            int h = (V - 1) / 2;
-            if (!(V & 1) && v < V / 2) ++h;
-            const int s0 = v + 1 >= V ? 0 : v + 1;
-            if (s0 + h <= V) {
-                rng0 = span(s0, h);
-                rng1 = span(0, 0);
-            } else {
-                rng0 = span(s0, V - s0);
-                rng1 = span(0, s0 + h - V);
-            }
-        }
-        col_tiles = rng0.tiles + rng1.tiles;
+        const int64_t base0 = a.rng[0].col_base;
+        rng0 = ColRange{z_all + sp.a0 * a.ld, sp.a1 - sp.a0, base0 + sp.a0, (int)((sp.a1 - sp.a0 + BN - 1) / BN)};
+        rng1 = ColRange{z_all + sp.b0 * a.ld, sp.b1 - sp.b0, base0 + sp.b0, (int)((sp.b1 - sp.b0 + BN - 1) / BN)};
     }
-    const int tile_begin = (int)(((int64_t)col_tiles * split) / a.splits);
-    const int tile_end = (int)(((int64_t)col_tiles * (split + 1)) / a.splits);
     const int64_t q0 = (int64_t)rb * BM;
+    if (!first_segment) __syncthreads();  // the lists of the previous row block have been written out by every wave
+    first_segment = false;
 
     const bool dead_row = LIST_GLOBAL && q0 + lrow >= a.nq;
     if (tid < BM) {
         mkey_all[tid] = (LIST_GLOBAL && q0 + tid >= a.nq) ? ~0ull : sentinel_key(a.min_similarity);
         cnt_all[tid] = 0u;
     }
-    if (COLSIDE && tid == 0) *lcnt = 0u;
     if (LIST_GLOBAL) {
         int64_t rows = a.nq - (q0 + wave * 32);
         rows = rows < 0 ? 0 : rows > 32 ? 32 : rows;
@@ -970,11 +1014,6 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
     float thr = dead_row ? INFINITY : a.min_similarity;
     float gbf = a.min_similarity;
     unsigned* my_gb = (q0 + lrow < a.nq) ? reinterpret_cast<unsigned*>(a.bound + q0 + lrow) + 1 : nullptr;  // score word
-    float* scratch = scratch_all + wave * (DMA_SLOTS * 64);
-
-    const int nkb = a.d / BK;
-    const int total = (tile_end - tile_begin) * nkb;
-
     // ---- query fragments: lane = row lrow, 16 bytes at k = 8 t + 4 half of every 8-deep step ----
     unsigned qoff;
     {
@@ -982,9 +1021,6 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
         if (q0 + r > a.nq - 1) r = a.nq - 1 - q0;
         qoff = (unsigned)((r * a.ld + half * 4) * 4);
     }
-    // ---- column tile: thread t moves, in round i, the 16 bytes that land at LDS byte
-    // i*4096 + t*16 of the buffer = row i*32 + t/8, slot t%8; the slot holds chunk slot ^ swizzle ----
-    const int c_chunk = (tid & 7) ^ ((tid >> 4) & 7);  // (row >> 1) & 7 == (t >> 4) & 7 for every round
     unsigned coff[4];
     const char* tile_ptr = nullptr;  // first row of the current column tile (uniform)
     u64 cb_key = 0ull;               // column side: bound key of column show tid of the tile set last
@@ -1030,18 +1066,6 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
 #pragma unroll
         for (int t = 0; t < 4; ++t) q[t] = *reinterpret_cast<const f32x4*>(qb + off + t * 32);
     };
-    // ---- fragment reads of the column tile: row (lane & 31) + 32 j, chunk 2 t + half ----
-    unsigned foff[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-        foff[t] = (unsigned)((lane & 31) * 128 + (((2 * t + half) ^ (((lane & 31) >> 1) & 7)) << 4));
-
-    f32x16 acc[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-
     // One k-block: the MFMAs of the tile in `cur` with the query fragments `q`; its transfers for the
     // next k-block were issued by the caller.  Fragment reads run one 8-deep step ahead.
     auto mfma_block = [&](const float* cur, const f32x4(&q)[4]) __attribute__((always_inline)) {
@@ -1071,11 +1095,9 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
         }
     };
 
-    if (tile_begin < tile_end) {
-        set_tile(tile_begin);
-        dma_tile(0, tileC0);
-        load_q(0, qreg[0]);
-    }
+    set_tile(tile_begin);
+    dma_tile(0, tileC0);
+    load_q(0, qreg[0]);
     __syncthreads();  // lists initialised, first k-block in place
 
     // k-blocks go in pairs (the host guarantees an even number per tile): A reads buffer 0 / set 0
@@ -1276,14 +1298,8 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
             __syncthreads();
         }
     }
-    if (COLSIDE) {  // what is still queued (the loop ended with a barrier)
-        __syncthreads();
-        unsigned queued_cols = *lcnt;
-        if (queued_cols > (unsigned)a.col_lds) queued_cols = (unsigned)a.col_lds;
-        for (unsigned i = tid; i < queued_cols; i += TOPK_THREADS) col_append(a, lrowg[i], lkey[i]);
-    }
 
-    // ---- final compaction and publication of this split's lists (per wave) ----
+    // ---- final compaction and publication of this segment's lists (per wave) ----
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const u64 empty = sentinel_key(a.min_similarity);
@@ -1302,6 +1318,13 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
         const int have = (int)cnt_all[row];
         u64* dst = a.partial + ((int64_t)split * a.nq + qr) * a.k;
         for (int i = lane; i < a.k; i += 64) dst[i] = i < have ? buf_all[(size_t)row * a.cap + i] : empty;
+    }
+    }  // segments
+    if (COLSIDE) {  // what is still queued (the last tile loop ended with a barrier)
+        __syncthreads();
+        unsigned queued_cols = *lcnt;
+        if (queued_cols > (unsigned)a.col_lds) queued_cols = (unsigned)a.col_lds;
+        for (unsigned i = tid; i < queued_cols; i += TOPK_THREADS) col_append(a, lrowg[i], lkey[i]);
     }
 }
 
@@ -1782,6 +1805,77 @@ static int max_merge_slots(int k) { return k < 1 ? 0 : FIN_MAX_KEYS / k; }
 
 static int tiles_of(int64_t n) { return (int)((n + BN - 1) / BN); }
 
+// Shards of the symmetric sweep: few enough that the own-columns sweep gives every show a bound
+// from >= 1024 columns, many enough that this sweep (1 / shards of all pairs, both orders
+// computed) stays small.  TVBF_SYM_SHARDS overrides (tuning / test aid).
+static int sym_shards(int row_blocks) {
+    int shards = row_blocks / 8 < 48 ? row_blocks / 8 : 48;
+    if (const char* e = getenv("TVBF_SYM_SHARDS")) shards = atoi(e);
+    if (shards > row_blocks) shards = row_blocks;
+    if (shards > MAX_SHARDS) shards = MAX_SHARDS;
+    return shards;
+}
+
+// Work of an LDS-DMA launch (see TopkArgs): fills the shard table and the item count, returns the
+// list slots the launch writes per row (the largest number of workgroup stretches that can cut
+// one row block), or 0 when there is nothing to sweep.  `sym` = SYM_OFF: one "shard" of all row
+// blocks with col_tiles tiles each; otherwise `shards` shards whose tiles follow from shard_spans().
+static int plan_items(TopkArgs* a, int sym, int64_t nq, int shards, int64_t n_all, int col_tiles, int cus,
+                      int wg_per_cu, int max_slots) {
+    const int RB = (int)((nq + BM - 1) / BM);
+    a->row_blocks = RB;
+    int t_max = 0;
+    if (sym == SYM_OFF) {
+        a->n_sh = 1;
+        a->sh_block0[0] = 0;
+        a->sh_tiles[0] = col_tiles;
+        a->sh_prefix[0] = 0;
+        a->sh_prefix[1] = (int64_t)RB * col_tiles;
+        t_max = col_tiles;
+    } else {
+        a->n_sh = shards;
+        a->sh_prefix[0] = 0;
+        for (int v = 0; v < shards; ++v) {
+            const ShardSpans sp = shard_spans(sym, v, shards, RB, n_all);
+            const int tiles = (int)((sp.a1 - sp.a0 + BN - 1) / BN) + (int)((sp.b1 - sp.b0 + BN - 1) / BN);
+            a->sh_block0[v] = (int)(((int64_t)v * RB) / shards);
+            const int blocks = (int)(((int64_t)(v + 1) * RB) / shards) - a->sh_block0[v];
+            a->sh_tiles[v] = tiles;
+            a->sh_prefix[v + 1] = a->sh_prefix[v] + (int64_t)blocks * tiles;
+            if (tiles > t_max) t_max = tiles;
+        }
+    }
+    const int64_t total = a->sh_prefix[a->n_sh];
+    a->total_tiles = total;
+    if (total <= 0) {
+        a->items = 0;
+        return 0;
+    }
+    int64_t items = (int64_t)cus * wg_per_cu;  // every workgroup resident at once, all with the same amount of work
+    if (const char* e = getenv("TVBF_ITEMS")) {  // tuning aid; any value gives the same result
+        const int64_t vset = atoll(e);
+        if (vset >= 1) items = vset;
+    }
+    if (items > total) items = total;
+    if (max_slots < 1) max_slots = 1;
+    for (;;) {
+        const int64_t len = total / items;  // shortest stretch
+        const int pieces = (int)((t_max + len - 1) / len) + 1;
+        if (pieces <= max_slots || items == 1) {
+            a->items = (int)items;
+            return pieces <= max_slots ? pieces : max_slots;
+        }
+        items = items * 3 / 4 > 0 ? items * 3 / 4 : 1;
+    }
+}
+
+// lists that no stretch writes (a row block cut fewer times than the most) must read as empty
+static void clear_slots(u64* lists, int64_t nq, int k, int slots, hipStream_t st) {
+    const int64_t words = (int64_t)slots * nq * k * 2;
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st,
+                       reinterpret_cast<unsigned*>(lists), words, 0u);
+}
+
 // LDS of the sweeps with a column side: the lists (at most 34 entries per row, so that the queue
 // fits for every k <= 24), the tile's column bounds and a queue of (key, show) entries in what is
 // left of half a CU's LDS.  Returns the queue entries (0: does not fit), the dynamic LDS bytes of
@@ -1855,7 +1949,13 @@ int tvbf_normalize_blocks_f32(const float* X, int64_t n, int64_t d, int64_t ldx,
 size_t tvbf_topk_workspace_bytes(int64_t nq, int64_t n, int64_t d, int k) {
     if (nq < 1 || n < 1 || k < 1 || k > TVBF_MAX_K) return 0;
     const Plan p = make_plan(nq, tiles_of(n), d, k, device_cus(), max_merge_slots(k));
-    return ws_bound_bytes(nq) + (size_t)p.splits * ws_slot_bytes(nq, k);
+    int slots = p.splits;
+    if (topk_use_dma(d)) {
+        TopkArgs a;
+        memset(&a, 0, sizeof(a));
+        slots = plan_items(&a, SYM_OFF, nq, 1, 0, tiles_of(n), device_cus(), p.wg_per_cu, max_merge_slots(k));
+    }
+    return ws_bound_bytes(nq) + (size_t)slots * ws_slot_bytes(nq, k);
 }
 
 size_t tvbf_topk_workspace_bytes_for_slots(int64_t nq, int k, int slots) {
@@ -1951,12 +2051,19 @@ static int accumulate_impl(const float* Zq, int64_t nq, int64_t q_row0, int64_t 
             return fail(TVBF_E_BAD_SHAPE, "the column side needs d %% 64 == 0 and k <= 24");
         if (gate) return fail(TVBF_E_BAD_ARG, "a gated sweep has no column side");
     }
-    const size_t need = ws_bound_bytes(nq) + (size_t)(slot0 + p.splits) * ws_slot_bytes(nq, k);
-    if (workspace_bytes < need) return fail(TVBF_E_BAD_SHAPE, "workspace must be >= %zu bytes", need);
-    const int64_t grid = (int64_t)p.row_blocks * p.splits;
-    if (grid > INT32_MAX) return fail(TVBF_E_BAD_ARG, "too many workgroups");
     const bool list_global = topk_list_global(k), dma = topk_use_dma(d);
     if (gate && !dma) return fail(TVBF_E_BAD_SHAPE, "a gated sweep needs d %% 64 == 0");
+    TopkArgs a;
+    memset(&a, 0, sizeof(a));
+    int slots = p.splits;
+    int64_t grid = (int64_t)p.row_blocks * p.splits;
+    if (dma) {  // equal stretches of the line of tiles, one per resident workgroup
+        slots = plan_items(&a, SYM_OFF, nq, 1, 0, tiles, device_cus(), p.wg_per_cu, max_slots);
+        grid = a.items;
+    }
+    const size_t need = ws_bound_bytes(nq) + (size_t)(slot0 + slots) * ws_slot_bytes(nq, k);
+    if (workspace_bytes < need) return fail(TVBF_E_BAD_SHAPE, "workspace must be >= %zu bytes", need);
+    if (grid > INT32_MAX) return fail(TVBF_E_BAD_ARG, "too many workgroups");
     const void* kernel =
         cs  ? reinterpret_cast<const void*>(cosine_topk_dma_kernel<false, SYM_OFF, true>)
         : dma ? (list_global ? reinterpret_cast<const void*>(cosine_topk_dma_kernel<true>)
@@ -1965,8 +2072,6 @@ static int accumulate_impl(const float* Zq, int64_t nq, int64_t q_row0, int64_t 
                              : reinterpret_cast<const void*>(cosine_tile_kernel<MODE_TOPK>));
     if (p.lds_bytes > 32 * 1024)
         HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
-    TopkArgs a;
-    memset(&a, 0, sizeof(a));
     a.zq = Zq;
     a.rng[0] = ColRange{ZcA, nA, colA, tiles_of(nA)};
     a.rng[1] = ColRange{nB ? ZcB : ZcA, nB, colB, nB ? tiles_of(nB) : 0};
@@ -1985,6 +2090,7 @@ static int accumulate_impl(const float* Zq, int64_t nq, int64_t q_row0, int64_t 
     a.min_similarity = min_similarity;
     a.exclude_self = exclude_self;
     a.gate = gate;
+    if (dma) clear_slots(a.partial, nq, k, slots, (hipStream_t)stream);
     if (cs) {
         char* st = reinterpret_cast<char*>(cs->state);
         a.col_bound = reinterpret_cast<const u64*>(cs->col_bound);
@@ -2014,7 +2120,7 @@ static int accumulate_impl(const float* Zq, int64_t nq, int64_t q_row0, int64_t 
         hipLaunchKernelGGL(cosine_tile_kernel<MODE_TOPK>, dim3((unsigned)grid), dim3(TOPK_THREADS), p.lds_bytes,
                            (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
-    *slots_used = p.splits;
+    *slots_used = slots;
     return TVBF_OK;
 }
 
@@ -2060,26 +2166,26 @@ int tvbf_topk_accumulate_sym_f32(const float* Zq, int64_t nq, int64_t q_row0, in
     int half_cap = 0;
     const int col_lds = colside_queue(k, d, &lds_half, &half_cap);
     const int row_blocks = (int)((nq + BM - 1) / BM);
-    int shards = row_blocks / 8 < 48 ? row_blocks / 8 : 48;
-    if (const char* e = getenv("TVBF_SYM_SHARDS")) shards = atoi(e);
-    if (shards > row_blocks) shards = row_blocks;
+    int shards = sym_shards(row_blocks);
     if (!col_lds || shards < 2)
         return fail(TVBF_E_BAD_SHAPE, "the symmetric sweep needs d %% 64 == 0, k <= 24 and at least 16 row blocks");
+    if (shards > MAX_SHARDS) shards = MAX_SHARDS;
     const int cus = device_cus();
-    const int sh_blocks = (row_blocks + shards - 1) / shards;
     int budget = max_slots - 1;  // one slot is the reduced column side
     if (budget < 2) return fail(TVBF_E_BAD_ARG, "the symmetric sweep needs at least 3 slots");
-    const Plan pd = make_plan(nq, sh_blocks, d, k, cus, budget / 2 > 4 ? 4 : budget / 2);
-    const Plan ph = make_plan(nq, (shards - 1) * sh_blocks / 2 + 1, d, k, cus, budget - pd.splits);
-    const int total = pd.splits + ph.splits + 1;
+    const size_t lds_diag = topk_lds_bytes(k, d);
+    TopkArgs a, ah;
+    memset(&a, 0, sizeof(a));
+    const int s_diag = plan_items(&a, SYM_DIAG, nq, shards, nq, 0, cus, 2, budget / 2);
+    ah = a;
+    const int s_half = plan_items(&ah, SYM_HALF, nq, shards, nq, 0, cus, 2, budget - s_diag);
+    const int total = s_diag + s_half + 1;
     const size_t need = ws_bound_bytes(nq) + (size_t)(slot0 + total) * ws_slot_bytes(nq, k);
     if (workspace_bytes < need) return fail(TVBF_E_BAD_SHAPE, "workspace must be >= %zu bytes", need);
 
     hipStream_t st = (hipStream_t)stream;
     char* ws = reinterpret_cast<char*>(workspace);
     char* cst = reinterpret_cast<char*>(colside->state);
-    TopkArgs a;
-    memset(&a, 0, sizeof(a));
     a.zq = Zq;
     a.rng[0] = ColRange{Zq, nq, q_row0, tiles_of(nq)};
     a.rng[1] = ColRange{Zq, 0, 0, 0};
@@ -2104,20 +2210,26 @@ int tvbf_topk_accumulate_sym_f32(const float* Zq, int64_t nq, int64_t q_row0, in
     u64* lists = reinterpret_cast<u64*>(ws + ws_bound_bytes(nq)) + (size_t)slot0 * nq * k;
     const void* k_diag = reinterpret_cast<const void*>(cosine_topk_dma_kernel<false, SYM_DIAG>);
     const void* k_half = reinterpret_cast<const void*>(cosine_topk_dma_kernel<false, SYM_HALF>);
-    HIP_TRY(hipFuncSetAttribute(k_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pd.lds_bytes));
+    HIP_TRY(hipFuncSetAttribute(k_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag));
     HIP_TRY(hipFuncSetAttribute(k_half, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_half));
+    clear_slots(lists, nq, k, s_diag + s_half, st);
     a.partial = lists;
-    a.splits = pd.splits;
-    hipLaunchKernelGGL((cosine_topk_dma_kernel<false, SYM_DIAG>), dim3((unsigned)(row_blocks * pd.splits)),
-                       dim3(TOPK_THREADS), pd.lds_bytes, st, a);
-    a.partial = lists + (size_t)pd.splits * nq * k;
-    a.splits = ph.splits;
+    if (a.items > 0)
+        hipLaunchKernelGGL((cosine_topk_dma_kernel<false, SYM_DIAG>), dim3((unsigned)a.items), dim3(TOPK_THREADS),
+                           lds_diag, st, a);
+    // the half sweep: same arguments, its own shard table, the lists capped for the column queue
+    a.items = ah.items, a.n_sh = ah.n_sh, a.total_tiles = ah.total_tiles;
+    memcpy(a.sh_block0, ah.sh_block0, sizeof(a.sh_block0));
+    memcpy(a.sh_tiles, ah.sh_tiles, sizeof(a.sh_tiles));
+    memcpy(a.sh_prefix, ah.sh_prefix, sizeof(a.sh_prefix));
+    a.partial = lists + (size_t)s_diag * nq * k;
     a.cap = half_cap;
-    hipLaunchKernelGGL((cosine_topk_dma_kernel<false, SYM_HALF>), dim3((unsigned)(row_blocks * ph.splits)),
-                       dim3(TOPK_THREADS), lds_half, st, a);
+    if (a.items > 0)
+        hipLaunchKernelGGL((cosine_topk_dma_kernel<false, SYM_HALF>), dim3((unsigned)a.items), dim3(TOPK_THREADS),
+                           lds_half, st, a);
     hipLaunchKernelGGL(col_reduce_kernel, dim3((unsigned)((nq + COLRED_ROWS - 1) / COLRED_ROWS)), dim3(64 * COLRED_ROWS),
                        0, st, a.col_cnt, a.col_buf, a.col_cap, a.col_bound, nq, k, min_similarity,
-                       lists + (size_t)(pd.splits + ph.splits) * nq * k, q_row0);
+                       lists + (size_t)(s_diag + s_half) * nq * k, q_row0);
     HIP_TRY(hipGetLastError());
     *slots_used = total;
     return TVBF_OK;
@@ -2241,45 +2353,35 @@ int tvbf_cosine_topk_f32(const float* Zq, int64_t nq, int64_t q_row0, const floa
 // lists instead.  No host synchronisation anywhere.
 struct SymPlan {
     bool ok;
-    int row_blocks, shards;
-    int s_diag, s_half, s_full;  // column splits (= list slots) of the three sweeps
-    int col_cap, col_lds, half_cap;
-    size_t lds_diag, lds_half;
-    size_t off_cnt, off_flag, off_buf, bytes;
+    int s_sym, s_full;  // list slots of the symmetric sweeps (own-columns + half + reduced column side) and of the plain re-run
+    int col_cap;
+    size_t topk_bytes;  // bounds and list slots: an ordinary top-K workspace
+    size_t off_state, state_bytes, bytes;  // the column-side state behind it
 };
 
 static SymPlan make_sym_plan(int64_t n, int64_t d, int k) {
     SymPlan sp;
     memset(&sp, 0, sizeof(sp));
-    if (n < 1 || k < 1 || k > TVBF_MAX_K || !topk_use_dma(d) || topk_list_global(k)) return sp;
-    sp.row_blocks = (int)((n + BM - 1) / BM);
-    // shards: few enough that the own-columns sweep gives every show a bound from >= 1024
-    // columns, many enough that this sweep (1 / shards of all pairs, computed twice) stays small
-    int target = sp.row_blocks / 8 < 48 ? sp.row_blocks / 8 : 48;
-    if (const char* e = getenv("TVBF_SYM_SHARDS")) target = atoi(e);  // tuning / test aid
-    if (target < 2) target = 2;
-    sp.shards = target < sp.row_blocks ? target : sp.row_blocks;
-    if (sp.shards < 2) return sp;
-    const int sh_blocks = (sp.row_blocks + sp.shards - 1) / sp.shards;  // the larger shards
+    if (n < 1 || k < 1 || k > TVBF_MAX_K) return sp;
+    const int row_blocks = (int)((n + BM - 1) / BM);
+    const int shards = sym_shards(row_blocks);
+    if (shards < 2 || !colside_queue(k, d, nullptr, nullptr)) return sp;
     const int cus = device_cus();
     const int slots = max_merge_slots(k);
-    sp.s_diag = make_plan(n, sh_blocks, d, k, cus, slots).splits;
-    sp.s_half = make_plan(n, (sp.shards - 1) * sh_blocks / 2 + 1, d, k, cus, slots).splits;
-    const Plan full = make_plan(n, tiles_of(n), d, k, cus, slots);
-    sp.s_full = full.splits;
-    if (sp.s_diag + sp.s_half + 1 > slots || sp.s_full > slots) return sp;
-    sp.lds_diag = full.lds_bytes;
-    sp.col_lds = colside_queue(k, d, &sp.lds_half, &sp.half_cap);
-    if (!sp.col_lds) return sp;
-    sp.col_cap = 1024;
+    TopkArgs a;
+    memset(&a, 0, sizeof(a));
+    const int s_diag = plan_items(&a, SYM_DIAG, n, shards, n, 0, cus, 2, (slots - 1) / 2);
+    const int s_half = plan_items(&a, SYM_HALF, n, shards, n, 0, cus, 2, slots - 1 - s_diag);
+    sp.s_sym = s_diag + s_half + 1;
+    sp.s_full = plan_items(&a, SYM_OFF, n, 1, 0, tiles_of(n), cus, 2, slots);
+    sp.col_cap = COL_CAP_MAX;
     if (const char* e = getenv("TVBF_SYM_COL_CAP")) sp.col_cap = atoi(e);  // tuning / test aid
     if (sp.col_cap < 1) sp.col_cap = 1;
     if (sp.col_cap > COL_CAP_MAX) sp.col_cap = COL_CAP_MAX;
-    const int lists = sp.s_diag + sp.s_half + 1 + sp.s_full;
-    sp.off_cnt = ws_bound_bytes(n) + (size_t)lists * ws_slot_bytes(n, k);
-    sp.off_flag = sp.off_cnt + ws_cnt_bytes(n);
-    sp.off_buf = sp.off_flag + 16;
-    sp.bytes = sp.off_buf + (size_t)n * sp.col_cap * 8;
+    sp.topk_bytes = ws_bound_bytes(n) + (size_t)(sp.s_sym + sp.s_full) * ws_slot_bytes(n, k);
+    sp.off_state = (sp.topk_bytes + 15) / 16 * 16;
+    sp.state_bytes = cs_buf_off(n) + (size_t)n * sp.col_cap * 8;
+    sp.bytes = sp.off_state + sp.state_bytes;
     sp.ok = true;
     return sp;
 }
@@ -2299,96 +2401,48 @@ int tvbf_cosine_topk_sym_f32(const float* Z, int64_t n, int64_t d, int64_t ld, i
     if (rc) return rc;
     const SymPlan sp = make_sym_plan(n, d, k);
     if (!sp.ok)
-        return fail(TVBF_E_BAD_SHAPE, "the symmetric sweep needs d %% 64 == 0, k <= 24 and at least two shards of rows");
+        return fail(TVBF_E_BAD_SHAPE, "the symmetric sweep needs d %% 64 == 0, k <= 24 and at least 16 blocks of 128 rows");
     if (workspace_bytes < sp.bytes) return fail(TVBF_E_BAD_SHAPE, "workspace must be >= %zu bytes", sp.bytes);
-    if (min_similarity < -FLT_MAX) min_similarity = -FLT_MAX;
-    hipStream_t st = (hipStream_t)stream;
+    // the pieces of the incremental interface in a row: bounds, own block symmetric (which here is
+    // the whole catalogue), the plain sweep behind the overflow gate, the merge
     char* ws = reinterpret_cast<char*>(workspace);
-    u64* bound = reinterpret_cast<u64*>(ws);
-    unsigned* col_cnt = reinterpret_cast<unsigned*>(ws + sp.off_cnt);
-    unsigned* flag = reinterpret_cast<unsigned*>(ws + sp.off_flag);
-    u64* col_buf = reinterpret_cast<u64*>(ws + sp.off_buf);
-    u64* lists = reinterpret_cast<u64*>(ws + ws_bound_bytes(n));
-    const size_t slot_keys = (size_t)n * k;
-
-    hipLaunchKernelGGL(bound_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, bound, n,
-                       sentinel_key(min_similarity));
-    // counters and the flag behind them are one stretch of the workspace
-    const int64_t words = (int64_t)((sp.off_buf - sp.off_cnt) / 4);
-    hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, col_cnt, words, 0u);
-
-    TopkArgs a;
-    memset(&a, 0, sizeof(a));
-    a.zq = Z;
-    a.rng[0] = ColRange{Z, n, 0, tiles_of(n)};
-    a.rng[1] = ColRange{Z, 0, 0, 0};
-    a.bound = bound;
-    a.nq = n;
-    a.q_row0 = 0;
-    a.ld = ld;
-    a.d = (int)d;
-    a.k = k;
-    a.cap = topk_cap(k, d);
-    a.row_blocks = sp.row_blocks;
-    a.col_tiles = tiles_of(n);
-    a.min_similarity = min_similarity;
-    a.exclude_self = exclude_self;
-    a.shards = sp.shards;
-    a.col_bound = bound;
-    a.col_cnt = col_cnt;
-    a.col_buf = col_buf;
-    a.col_cap = sp.col_cap;
-    a.col_lds = sp.col_lds;
-    a.overflow = flag;
-
-    const void* k_diag = reinterpret_cast<const void*>(cosine_topk_dma_kernel<false, SYM_DIAG>);
-    const void* k_half = reinterpret_cast<const void*>(cosine_topk_dma_kernel<false, SYM_HALF>);
-    const void* k_full = reinterpret_cast<const void*>(cosine_topk_dma_kernel<false, SYM_OFF>);
-    HIP_TRY(hipFuncSetAttribute(k_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.lds_diag));
-    HIP_TRY(hipFuncSetAttribute(k_half, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.lds_half));
-    HIP_TRY(hipFuncSetAttribute(k_full, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.lds_diag));
-
-    a.partial = lists;
-    a.splits = sp.s_diag;
-    hipLaunchKernelGGL((cosine_topk_dma_kernel<false, SYM_DIAG>), dim3((unsigned)(sp.row_blocks * sp.s_diag)),
-                       dim3(TOPK_THREADS), sp.lds_diag, st, a);
-    a.partial = lists + (size_t)sp.s_diag * slot_keys;
-    a.splits = sp.s_half;
-    a.cap = sp.half_cap;
-    hipLaunchKernelGGL((cosine_topk_dma_kernel<false, SYM_HALF>), dim3((unsigned)(sp.row_blocks * sp.s_half)),
-                       dim3(TOPK_THREADS), sp.lds_half, st, a);
-    hipLaunchKernelGGL(col_reduce_kernel, dim3((unsigned)((n + COLRED_ROWS - 1) / COLRED_ROWS)), dim3(64 * COLRED_ROWS),
-                       0, st, col_cnt, col_buf, sp.col_cap, bound, n, k, min_similarity,
-                       lists + (size_t)(sp.s_diag + sp.s_half) * slot_keys, (int64_t)0);
-    // the complete plain sweep: a no-op unless a buffer overflowed
-    const int first_full = sp.s_diag + sp.s_half + 1;
-    a.partial = lists + (size_t)first_full * slot_keys;
-    a.splits = sp.s_full;
-    a.cap = topk_cap(k, d);
-    a.gate = flag;
-    hipLaunchKernelGGL((cosine_topk_dma_kernel<false, SYM_OFF>), dim3((unsigned)(sp.row_blocks * sp.s_full)),
-                       dim3(TOPK_THREADS), sp.lds_diag, st, a);
-    hipLaunchKernelGGL(topk_finalize_kernel, dim3((unsigned)((n + FIN_ROWS - 1) / FIN_ROWS)), dim3(64 * FIN_ROWS), 0, st,
-                       lists, n, k, first_full, out_idx, out_score, out_count, flag, first_full, sp.s_full,
-                       (const u64*)nullptr, 0, (int64_t)0);
-    HIP_TRY(hipGetLastError());
-    return TVBF_OK;
+    tvbf_colside cs;
+    cs.col_bound = nullptr;
+    cs.state = ws + sp.off_state;
+    cs.state_bytes = sp.state_bytes;
+    cs.n_total = n;
+    cs.cap = sp.col_cap;
+    const uint32_t* flag = reinterpret_cast<const uint32_t*>(cs.state);
+    rc = tvbf_topk_begin(n, k, min_similarity, workspace, sp.topk_bytes, stream);
+    if (rc) return rc;
+    rc = tvbf_topk_colside_begin(cs.state, cs.state_bytes, n, cs.cap, stream);
+    if (rc) return rc;
+    int used = 0, used_full = 0;
+    rc = tvbf_topk_accumulate_sym_f32(Z, n, 0, d, ld, k, min_similarity, exclude_self, workspace, sp.topk_bytes, 0,
+                                      sp.s_sym, &used, &cs, stream);
+    if (rc) return rc;
+    rc = accumulate_impl(Z, n, 0, d, ld, Z, n, 0, nullptr, 0, 0, k, min_similarity, exclude_self, workspace,
+                         sp.topk_bytes, used, sp.s_full, &used_full, nullptr, flag, stream);
+    if (rc) return rc;
+    return tvbf_topk_finish_ex(n, k, used, nullptr, 0, 0, flag, used, used_full, out_idx, out_score, out_count,
+                               workspace, sp.topk_bytes, stream);
 }
 
 int tvbf_cosine_topk_sym_inspect(const void* workspace, int64_t n, int64_t d, int k, int64_t* out4, void* stream) {
     if (!workspace || !out4) return fail(TVBF_E_BAD_ARG, "null pointer argument");
     const SymPlan sp = make_sym_plan(n, d, k);
     if (!sp.ok) return fail(TVBF_E_BAD_SHAPE, "not a shape of the symmetric sweep");
-    std::vector<unsigned> host((sp.off_buf - sp.off_cnt) / 4);
-    HIP_TRY(hipMemcpyAsync(host.data(), reinterpret_cast<const char*>(workspace) + sp.off_cnt, host.size() * 4,
+    std::vector<unsigned> host(cs_buf_off(n) / 4);  // flag words, then one counter per show
+    HIP_TRY(hipMemcpyAsync(host.data(), reinterpret_cast<const char*>(workspace) + sp.off_state, host.size() * 4,
                            hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    const unsigned* cnt = host.data() + cs_cnt_off() / 4;
     int64_t total = 0, worst = 0, worst_row = -1;
     for (int64_t i = 0; i < n; ++i) {
-        total += host[i];
-        if ((int64_t)host[i] > worst) worst = host[i], worst_row = i;
+        total += cnt[i];
+        if ((int64_t)cnt[i] > worst) worst = cnt[i], worst_row = i;
     }
-    out4[0] = host[(sp.off_flag - sp.off_cnt) / 4];
+    out4[0] = host[0];
     out4[1] = total;
     out4[2] = worst;
     out4[3] = worst_row;
