@@ -157,9 +157,10 @@ int tvbf_cosine_topk_f32(const float* Zq, int64_t nq, int64_t q_row0, const floa
  *               n large enough for two shards of 128-row blocks
  *   workspace   >= tvbf_cosine_topk_sym_workspace_bytes(n, d, k) bytes, which returns 0 when
  *               the shape is not taken (call tvbf_cosine_topk_f32 then)
- * Every show has a buffer of 1024 column-side candidates; should one overflow (a thousand exact
- * ties at a show's K-th score), the call recomputes the plain way on the device, without host
- * synchronisation -- correct, at the plain sweep's cost on top.
+ * Every show has a buffer of 1024 column-side candidates; should one overflow, the show is
+ * flagged and a plain sweep restricted to the 128-row blocks that hold flagged shows recomputes
+ * their lists on the device, without host synchronisation (it returns at once when nothing is
+ * flagged).
  */
 size_t tvbf_cosine_topk_sym_workspace_bytes(int64_t n, int64_t d, int k);
 int tvbf_cosine_topk_sym_f32(const float* Z, int64_t n, int64_t d, int64_t ld, int k, float min_similarity,
@@ -167,9 +168,9 @@ int tvbf_cosine_topk_sym_f32(const float* Z, int64_t n, int64_t d, int64_t ld, i
                              void* workspace, size_t workspace_bytes, void* stream);
 /*
  * Diagnostics of the last tvbf_cosine_topk_sym_f32 call on `workspace` (synchronises the stream;
- * no counterpart in the reference): out4 = { 1 if a column buffer overflowed and the plain sweep
- * recomputed the lists, column-side candidates appended in total, the largest number appended
- * for one show, that show's row }.
+ * no counterpart in the reference): out4 = { shows whose column buffer overflowed (their lists
+ * came from the plain re-run), column-side candidates appended in total, the largest number
+ * appended for one show, that show's row }.
  */
 int tvbf_cosine_topk_sym_inspect(const void* workspace, int64_t n, int64_t d, int k, int64_t* out4,
                                  void* stream);
@@ -213,20 +214,24 @@ int tvbf_topk_finish(int64_t nq, int k, int slots, int32_t* out_idx, float* out_
  *   tvbf_colside            col_bound: device, n_total 64-bit keys (the per-row bounds that
  *                           start a top-K workspace: the best known lower bound of each row's
  *                           K-th key, gathered over all shards, indexed by global column); state / state_bytes: device buffer of
- *                           tvbf_topk_colside_bytes(n_total, cap) bytes whose first word is the
- *                           overflow flag; cap: candidates kept per show (<= 1024)
+ *                           tvbf_topk_colside_bytes(n_total, cap) bytes that starts with the
+ *                           overflow words: word 0 = some buffer overflowed, words 4 .. 4+n_total-1
+ *                           = this show's buffer overflowed; cap: candidates kept per show (<= 1024)
  *   tvbf_topk_colside_begin clears the counters and the flag
  *   tvbf_topk_accumulate_ex tvbf_topk_accumulate_f32 plus, with colside != NULL, the column side
  *                           (d % 64 == 0, k <= 24): a (score, global row) key above col_bound[column]
  *                           is appended to that column's buffer; with
- *                           gate != NULL the sweep runs only if *gate != 0 (device word; used
- *                           for the plain re-run after an overflow) and takes no column side
+ *                           gate != NULL (device, the overflow words of a column-side state,
+ *                           max-reduced over the shards) only the 128-row blocks that hold a
+ *                           flagged show are swept -- the plain re-run after an overflow -- and
+ *                           there is no column side
  *   tvbf_topk_colside_reduce  the K best buffered candidates of shows row0 .. row0+rows-1 as
  *                           partial lists (rows x k keys, the workspace slot format) into `lists`
  *   tvbf_topk_finish_ex     tvbf_topk_finish that also merges n_extra lists of nq x k keys found
  *                           at extra + e * extra_stride (keys), e.g. those received from the
- *                           shards that computed this shard's columns; with gate != NULL and
- *                           *gate != 0 it merges slots alt_first .. alt_first+alt_slots-1 alone
+ *                           shards that computed this shard's columns; with gate != NULL (device,
+ *                           the nq per-show overflow words OF THESE ROWS: overflow words + 4 +
+ *                           q_row0) a flagged row merges slots alt_first .. alt_first+alt_slots-1 alone
  */
 typedef struct tvbf_colside {
     const uint64_t* col_bound;

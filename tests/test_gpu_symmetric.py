@@ -43,7 +43,7 @@ def _sym(z, k, ms, expect_overflow=False, **kw):
     ws = torch.empty((nbytes + 15) // 16 * 2, dtype=torch.int64, device=z.device)
     top = engine.cosine_topk_symmetric(z, k, ms, workspace=ws, **kw)
     info = engine.symmetric_inspect(ws, n, ld, k)
-    assert info["overflowed"] == expect_overflow, info
+    assert (info["overflowed"] > 0) == expect_overflow, info
     assert info["appended"] > 0
     return top
 
@@ -208,7 +208,7 @@ def _lockstep_ranks(device, z, n, world, k, ms, col_cap=1024):
         tops.append(j.finish(z_all, recv, flag))
     torch.cuda.synchronize()
     cat = lambda f: torch.cat([getattr(t, f)[: sh.rows] for t, sh in zip(tops, shards)])  # noqa: E731
-    return engine.TopK(cat("idx"), cat("score"), cat("count")), int(flag.item())
+    return engine.TopK(cat("idx"), cat("score"), cat("count")), int(flag[0].item())
 
 
 @pytest.mark.parametrize("n,world", [(3000, 2), (3000, 3), (3000, 4), (5000, 8), (2049, 4), (700, 8), (1300, 5), (10, 8),

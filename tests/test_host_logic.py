@@ -398,7 +398,7 @@ def _sym_worker(rank, world, port, n, k, min_sim, ret):
                 return torch.zeros((1,), dtype=torch.int32)
 
             def finish(self, z_all, recv, flag):
-                assert int(flag.item()) == 0
+                assert int(flag.max().item()) == 0
                 rk = recv.numpy().view(np.uint64)
                 idx = -np.ones((self.sh.rows, self.k), np.int32)
                 score = np.zeros((self.sh.rows, self.k), np.float32)

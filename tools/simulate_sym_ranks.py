@@ -50,4 +50,4 @@ for rep in range(2):
 tot = [a + b + c + e for a, b, c, e in zip(t_own, t_half, t_red, t_fin)]
 for r in range(world):
     print(f"rank {r}: own {t_own[r]:.2f}  half {t_half[r]:.2f}  reduce {t_red[r]:.2f}  finish {t_fin[r]:.2f}  total {tot[r]:.2f} ms")
-print(f"world {world}: slowest rank {max(tot):.2f} ms, mean {sum(tot) / world:.2f} ms, overflow flag {int(flag.item())}")
+print(f"world {world}: slowest rank {max(tot):.2f} ms, mean {sum(tot) / world:.2f} ms, overflow flag {int(flag[0].item())}, flagged shows {int((flag[4:] != 0).sum().item())}")

@@ -153,6 +153,7 @@ struct ColRange {
 };
 
 constexpr int MAX_SHARDS = 64;
+constexpr int OVF_SHOWS = 4;  // word offset of the per-show overflow flags behind the summary word
 
 struct TopkArgs {
     const float* zq;
@@ -189,8 +190,9 @@ struct TopkArgs {
     unsigned* col_cnt;          // [shows] entries appended (may exceed col_cap: the rest was dropped)
     u64* col_buf;               // [shows][col_cap] keys (score, global row of the QUERY side)
     int col_cap, col_lds;       // entries per show; entries of the workgroup's LDS queue
-    unsigned* overflow;         // set to 1 when a show's buffer was full
-    const unsigned* gate;       // plain sweeps: skip all work unless *gate != 0 (null: always run)
+    unsigned* overflow;         // [0]: a buffer was full somewhere; [OVF_SHOWS + show]: this show's buffer was
+    const unsigned* gate;       // plain sweeps (null: always run): the same layout, indexed by global row --
+                                // only row blocks holding a flagged show are swept
 };
 
 // radix select of the median over ordered 32-bit keys: 11 + 11 + 10 bits
@@ -918,8 +920,10 @@ __device__ static inline void col_append(const TopkArgs& a, unsigned rowg, u64 k
     const unsigned p = atomicAdd(a.col_cnt + rowg, 1u);
     if (p < (unsigned)a.col_cap)
         a.col_buf[(int64_t)rowg * a.col_cap + p] = key;
-    else
+    else {  // dropped: the show's lists are recomputed by the gated plain sweep
+        __hip_atomic_store(a.overflow + OVF_SHOWS + rowg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(a.overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 template <bool LIST_GLOBAL, int SYM = SYM_OFF, bool COLSIDE = (SYM == SYM_HALF)>
@@ -991,8 +995,15 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
         rng1 = ColRange{z_all + sp.b0 * a.ld, sp.b1 - sp.b0, base0 + sp.b0, (int)((sp.b1 - sp.b0 + BN - 1) / BN)};
     }
     const int64_t q0 = (int64_t)rb * BM;
-    if (!first_segment) __syncthreads();  // the lists of the previous row block have been written out by every wave
-    first_segment = false;
+    if (SYM == SYM_OFF && !COLSIDE && a.gate) {
+        // gated sweep: only row blocks with a flagged show (the barrier also separates the segments)
+        const bool mine = tid < BM && q0 + tid < a.nq && a.gate[OVF_SHOWS + a.q_row0 + q0 + tid] != 0u;
+        first_segment = false;
+        if (!__syncthreads_or(mine ? 1 : 0)) continue;
+    } else {
+        if (!first_segment) __syncthreads();  // the lists of the previous row block have been written out by every wave
+        first_segment = false;
+    }
 
     const bool dead_row = LIST_GLOBAL && q0 + lrow >= a.nq;
     if (tid < BM) {
@@ -1340,8 +1351,8 @@ constexpr int FIN_MAX_KEYS = 2048;  // partial lists per row * k
 
 constexpr int FIN_ROWS = 2;  // rows (wavefronts) per workgroup
 
-// `gate` (may be null): when *gate != 0 the lists [alt_first, alt_first + alt_splits) are merged
-// instead of [0, splits) -- the symmetric sweep's complete re-run after a buffer overflow.
+// `gate` (may be null) points at the per-row overflow flags of these nq rows: a flagged row merges
+// the lists [alt_first, alt_first + alt_splits) -- the plain re-run of its row block -- instead.
 __global__ __launch_bounds__(64 * FIN_ROWS) void topk_finalize_kernel(const u64* __restrict__ partial, int64_t nq,
                                                             int k, int splits, int32_t* __restrict__ out_idx,
                                                             float* __restrict__ out_score,
@@ -1354,7 +1365,7 @@ __global__ __launch_bounds__(64 * FIN_ROWS) void topk_finalize_kernel(const u64*
     const int wave = threadIdx.x >> 6;
     const int64_t row = (int64_t)blockIdx.x * FIN_ROWS + wave;
     if (row >= nq) return;
-    if (gate && *gate != 0u) {
+    if (gate && gate[row] != 0u) {
         partial += (int64_t)alt_first * nq * k;
         splits = alt_splits;
         n_extra = 0;
@@ -1809,7 +1820,7 @@ static int tiles_of(int64_t n) { return (int)((n + BN - 1) / BN); }
 // from >= 1024 columns, many enough that this sweep (1 / shards of all pairs, both orders
 // computed) stays small.  TVBF_SYM_SHARDS overrides (tuning / test aid).
 static int sym_shards(int row_blocks) {
-    int shards = row_blocks / 8 < 48 ? row_blocks / 8 : 48;
+    int shards = row_blocks / 8 < 32 ? row_blocks / 8 : 32;
     if (const char* e = getenv("TVBF_SYM_SHARDS")) shards = atoi(e);
     if (shards > row_blocks) shards = row_blocks;
     if (shards > MAX_SHARDS) shards = MAX_SHARDS;
@@ -2007,9 +2018,10 @@ static int validate_accumulate(const float* Zq, int64_t nq, int64_t q_row0, int6
     return TVBF_OK;
 }
 
-// column-side state: [overflow flag, 16 bytes][n_total counters, padded to 16 bytes][n_total x cap keys]
-static size_t cs_cnt_off() { return 16; }
-static size_t cs_buf_off(int64_t n_total) { return 16 + ws_cnt_bytes(n_total); }
+// column-side state: [overflow summary word, 16 bytes][n_total per-show overflow flags][n_total counters]
+// (both padded to 16 bytes)[n_total x cap keys]
+static size_t cs_cnt_off(int64_t n_total) { return 16 + ws_cnt_bytes(n_total); }
+static size_t cs_buf_off(int64_t n_total) { return 16 + 2 * ws_cnt_bytes(n_total); }
 
 static int check_colside(const tvbf_colside* cs) {
     if (!cs->col_bound || !cs->state || ((uintptr_t)cs->state & 15))
@@ -2095,7 +2107,7 @@ static int accumulate_impl(const float* Zq, int64_t nq, int64_t q_row0, int64_t 
         char* st = reinterpret_cast<char*>(cs->state);
         a.col_bound = reinterpret_cast<const u64*>(cs->col_bound);
         a.overflow = reinterpret_cast<unsigned*>(st);
-        a.col_cnt = reinterpret_cast<unsigned*>(st + cs_cnt_off());
+        a.col_cnt = reinterpret_cast<unsigned*>(st + cs_cnt_off(cs->n_total));
         a.col_buf = reinterpret_cast<u64*>(st + cs_buf_off(cs->n_total));
         a.col_cap = cs->cap;
         a.col_lds = col_lds;
@@ -2203,7 +2215,7 @@ int tvbf_topk_accumulate_sym_f32(const float* Zq, int64_t nq, int64_t q_row0, in
     a.shards = shards;
     a.col_bound = a.bound - q_row0;  // indexed by global row; only this block's rows are ever read
     a.overflow = reinterpret_cast<unsigned*>(cst);
-    a.col_cnt = reinterpret_cast<unsigned*>(cst + cs_cnt_off());
+    a.col_cnt = reinterpret_cast<unsigned*>(cst + cs_cnt_off(colside->n_total));
     a.col_buf = reinterpret_cast<u64*>(cst + cs_buf_off(colside->n_total));
     a.col_cap = colside->cap;
     a.col_lds = col_lds;
@@ -2244,7 +2256,7 @@ int tvbf_topk_colside_begin(void* state, size_t state_bytes, int64_t n_total, in
     if (!state || ((uintptr_t)state & 15)) return fail(TVBF_E_BAD_ARG, "null or misaligned state");
     if (!tvbf_topk_colside_bytes(n_total, cap) || state_bytes < tvbf_topk_colside_bytes(n_total, cap))
         return fail(TVBF_E_BAD_SHAPE, "state smaller than tvbf_topk_colside_bytes()");
-    const int64_t words = (int64_t)(cs_buf_off(n_total) / 4);  // flag and counters
+    const int64_t words = (int64_t)(cs_buf_off(n_total) / 4);  // flags and counters
     hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<unsigned*>(state), words, 0u);
     HIP_TRY(hipGetLastError());
@@ -2263,7 +2275,7 @@ int tvbf_topk_colside_reduce(const tvbf_colside* cs, int64_t row0, int64_t rows,
     const char* st = reinterpret_cast<const char*>(cs->state);
     hipLaunchKernelGGL(col_reduce_kernel, dim3((unsigned)((rows + COLRED_ROWS - 1) / COLRED_ROWS)),
                        dim3(64 * COLRED_ROWS), 0, (hipStream_t)stream,
-                       reinterpret_cast<const unsigned*>(st + cs_cnt_off()),
+                       reinterpret_cast<const unsigned*>(st + cs_cnt_off(cs->n_total)),
                        reinterpret_cast<const u64*>(st + cs_buf_off(cs->n_total)), (int)cs->cap, reinterpret_cast<const u64*>(cs->col_bound), rows, k,
                        min_similarity, reinterpret_cast<u64*>(lists), row0);
     HIP_TRY(hipGetLastError());
@@ -2424,25 +2436,27 @@ int tvbf_cosine_topk_sym_f32(const float* Z, int64_t n, int64_t d, int64_t ld, i
     rc = accumulate_impl(Z, n, 0, d, ld, Z, n, 0, nullptr, 0, 0, k, min_similarity, exclude_self, workspace,
                          sp.topk_bytes, used, sp.s_full, &used_full, nullptr, flag, stream);
     if (rc) return rc;
-    return tvbf_topk_finish_ex(n, k, used, nullptr, 0, 0, flag, used, used_full, out_idx, out_score, out_count,
-                               workspace, sp.topk_bytes, stream);
+    return tvbf_topk_finish_ex(n, k, used, nullptr, 0, 0, flag + OVF_SHOWS, used, used_full, out_idx, out_score,
+                               out_count, workspace, sp.topk_bytes, stream);
 }
 
 int tvbf_cosine_topk_sym_inspect(const void* workspace, int64_t n, int64_t d, int k, int64_t* out4, void* stream) {
     if (!workspace || !out4) return fail(TVBF_E_BAD_ARG, "null pointer argument");
     const SymPlan sp = make_sym_plan(n, d, k);
     if (!sp.ok) return fail(TVBF_E_BAD_SHAPE, "not a shape of the symmetric sweep");
-    std::vector<unsigned> host(cs_buf_off(n) / 4);  // flag words, then one counter per show
+    std::vector<unsigned> host(cs_buf_off(n) / 4);  // summary, per-show flags, then one counter per show
     HIP_TRY(hipMemcpyAsync(host.data(), reinterpret_cast<const char*>(workspace) + sp.off_state, host.size() * 4,
                            hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    const unsigned* cnt = host.data() + cs_cnt_off() / 4;
+    const unsigned* cnt = host.data() + cs_cnt_off(n) / 4;
     int64_t total = 0, worst = 0, worst_row = -1;
     for (int64_t i = 0; i < n; ++i) {
         total += cnt[i];
         if ((int64_t)cnt[i] > worst) worst = cnt[i], worst_row = i;
     }
-    out4[0] = host[0];
+    int64_t flagged = 0;
+    for (int64_t i = 0; i < n; ++i) flagged += host[OVF_SHOWS + i] != 0;
+    out4[0] = flagged;
     out4[1] = total;
     out4[2] = worst;
     out4[3] = worst_row;

@@ -253,7 +253,7 @@ def symmetric_inspect(workspace: torch.Tensor, n: int, ld: int, k: int) -> dict:
     with torch.cuda.device(workspace.device):
         rc = native.load().tvbf_cosine_topk_sym_inspect(workspace.data_ptr(), int(n), int(ld), int(k), out, _stream_ptr())
     native.check(rc, "tvbf_cosine_topk_sym_inspect")
-    return {"overflowed": bool(out[0]), "appended": int(out[1]), "max_per_show": int(out[2]), "busiest_show": int(out[3])}
+    return {"overflowed": int(out[0]), "appended": int(out[1]), "max_per_show": int(out[2]), "busiest_show": int(out[3])}
 
 
 def catalogue_topk(z: torch.Tensor, k: int, min_similarity: float, *, n: int | None = None,
@@ -524,8 +524,9 @@ class TopkSession:
 
     def accumulate(self, range_a, range_b=None, max_slots: int = 16, *, colside=None, gate=None) -> int:
         """One fused launch over up to two column ranges.  ``colside=(ColumnSide, col_bound)`` also
-        hands the scores to the shows of the columns; ``gate`` (int32 device tensor) makes the
-        sweep conditional on a non-zero word -- the slots are reserved either way."""
+        hands the scores to the shows of the columns; ``gate`` (the overflow words of a ColumnSide,
+        int32 device tensor) restricts the sweep to the 128-row blocks that hold a flagged show --
+        the slots are reserved either way."""
         pa, na, ca, keep_a = self._range(range_a, self.ld)
         pb, nb, cb, keep_b = self._range(range_b, self.ld)
         if na + nb == 0 or self.nq == 0:
@@ -556,8 +557,8 @@ class TopkSession:
     def finish(self, out: TopK | None = None, *, extra: torch.Tensor | None = None, gate=None,
                alt: tuple[int, int] | None = None, slots: int | None = None) -> TopK:
         """Merge the partial lists of slots 0 .. slots-1 (default: all used) and of ``extra``
-        (int64 keys, (lists, rows >= nq, k) contiguous).  With ``gate`` and ``alt=(first, count)``
-        the slots first .. first+count-1 alone are merged when the gate word is non-zero."""
+        (int64 keys, (lists, rows >= nq, k) contiguous).  With ``gate`` (overflow words as for
+        accumulate) and ``alt=(first, count)`` a flagged row merges slots first .. first+count-1 alone."""
         if out is None:
             out = TopK(torch.empty((self.nq, self.k), dtype=torch.int32, device=self.dev),
                        torch.empty((self.nq, self.k), dtype=torch.float32, device=self.dev),
@@ -574,7 +575,7 @@ class TopkSession:
         gate_ptr, alt_first, alt_slots = None, 0, 0
         if gate is not None:
             _require_cuda(gate, "gate", dtype=torch.int32)
-            gate_ptr, (alt_first, alt_slots) = gate.data_ptr(), alt
+            gate_ptr, (alt_first, alt_slots) = gate.data_ptr() + 4 * (4 + self.q_row0), alt
         with torch.cuda.device(self.dev):
             rc = self.lib.tvbf_topk_finish_ex(self.nq, self.k, slots, extra_ptr, n_extra, stride, gate_ptr,
                                               alt_first, alt_slots, out.idx.data_ptr(), out.score.data_ptr(),
@@ -605,9 +606,9 @@ class ColumnSide:
         native.check(rc, "tvbf_topk_colside_begin")
 
     @property
-    def flag(self) -> torch.Tensor:
-        """The overflow word (int32 view, one element)."""
-        return self.state.view(torch.int32)[:1]
+    def flags(self) -> torch.Tensor:
+        """The overflow words (int32 view): [0] some buffer overflowed, [4 + show] this show's did."""
+        return self.state.view(torch.int32)[: 4 + self.n_total]
 
     def struct(self, col_bound: torch.Tensor):
         _require_cuda(col_bound, "col_bound", dtype=torch.int64)

@@ -181,7 +181,7 @@ class SymmetricShardJob:
                                upper partner of an even world also sweeps its rows [h0, rows)
                                against its partner's columns
         lists_for_peers(b)     -> (world, per_rank, k) int64: per peer the lists of ITS rows found here
-        flag                   -> overflow word, to be max-reduced over the ranks
+        flag                   -> overflow words, to be max-reduced over the ranks
         finish(z_all, recv, flag) gated plain re-run + merge of own lists and the received ones
     """
 
@@ -251,11 +251,13 @@ class SymmetricShardJob:
 
     @property
     def flag(self) -> torch.Tensor:
-        return self.side.flag
+        """Overflow words of this rank's column side (summary + one per show), to be max-reduced."""
+        return self.side.flags
 
     def finish(self, z_all: torch.Tensor, recv: torch.Tensor, flag: torch.Tensor, out=None):
-        """``flag``: the overflow word after the max-reduction (int32 device tensor).  The plain
-        sweep over all columns is launched in any case and returns at once while the flag is 0."""
+        """``flag``: the overflow words after the max-reduction (int32 device tensor).  The plain
+        sweep over all columns is launched in any case; it only touches row blocks that hold a
+        flagged show and returns at once when there is none."""
         sh = self.shard
         own, after, before = column_pieces(sh)
         first = self.session.used
@@ -306,7 +308,7 @@ def exchange_lists(send: torch.Tensor, group=None) -> torch.Tensor:
 
 
 def reduce_flag(flag: torch.Tensor, group=None) -> torch.Tensor:
-    """max over the ranks of a one-word tensor (a copy; the input is left alone)."""
+    """element-wise max over the ranks of a small tensor (a copy; the input is left alone)."""
     if _via_host(flag, group):
         host = flag.cpu()
         dist.all_reduce(host, op=dist.ReduceOp.MAX, group=group)
