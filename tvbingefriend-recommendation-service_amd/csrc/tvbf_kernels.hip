@@ -1255,47 +1255,56 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
                         for (int r = 0; r < 16; ++r) acc[j][r] = -INFINITY;
                 }
                 const unsigned my_row = (unsigned)(a.q_row0 + q0 + lrow);
+                // Scores that reach their column's bound are queued per lane (value in the wave's
+                // scratch, position in a 64-bit mask) over the WHOLE tile and handed on by one pop
+                // loop; a lane holds eight, so the queue is emptied early once a lane passes four
+                // (a group of four registers adds at most four).
+                u64 cbits = 0ull;
+                int cqueued = 0;
+                auto col_pop = [&]() {
+                    int slot = 0;
+                    while (__any(cbits != 0ull)) {
+                        const bool has = cbits != 0ull;
+                        const int idx = has ? __builtin_ctzll(cbits) : 0;
+                        cbits &= cbits - 1ull;
+                        const float v = scratch[slot * 64 + lane];
+                        ++slot;
+                        const int rowloc = 2 * (idx & 48) + (idx & 3) + 2 * (idx & 12) + 4 * half;  // 32 j + (r & 3) + 8 (r >> 2)
+                        const u64 key = make_key(v, (int)my_row);
+                        // equal scores: only a key above the show's K-th key can enter its list
+                        const u64 bkey = ((u64)f32_to_ordered(cbound[rowloc]) << 32) | cblo[rowloc];
+                        if (has && key > bkey) {
+                            const unsigned rowg = (unsigned)col0 + rowloc;
+                            const unsigned pos = atomicAdd(lcnt, 1u);
+                            if (pos < (unsigned)a.col_lds) {
+                                lkey[pos] = key;
+                                lrowg[pos] = rowg;
+                            } else {
+                                col_append(a, rowg, key);  // queue full: straight to the show's buffer
+                            }
+                        }
+                    }
+                    cqueued = 0;
+                };
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
 #pragma unroll
-                    for (int r0 = 0; r0 < 16; r0 += DMA_SLOTS) {
-                        const f32x4 cta = *reinterpret_cast<const f32x4*>(cbound + 32 * j + 2 * r0 + 4 * half);
-                        const f32x4 ctb = *reinterpret_cast<const f32x4*>(cbound + 32 * j + 2 * r0 + 8 + 4 * half);
-                        unsigned bits = 0u;
-                        int queued = 0;
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 ct = *reinterpret_cast<const f32x4*>(cbound + 32 * j + 8 * g + 4 * half);
 #pragma unroll
-                        for (int r = r0; r < r0 + DMA_SLOTS; ++r) {
-                            const float cthr = (r - r0) < 4 ? cta[r & 3] : ctb[r & 3];
-                            if (acc[j][r] >= cthr) {
+                        for (int u = 0; u < 4; ++u) {
+                            const int r = 4 * g + u;
+                            if (acc[j][r] >= ct[u]) {
                                 asm volatile("");  // keeps a real branch around the block
-                                scratch[queued * 64 + lane] = acc[j][r];
-                                ++queued;
-                                bits |= 1u << r;
+                                scratch[cqueued * 64 + lane] = acc[j][r];
+                                ++cqueued;
+                                cbits |= 1ull << (16 * j + r);
                             }
                         }
-                        if (__any(bits != 0u)) {
-                            int slot = 0;
-                            while (__any(bits != 0u)) {
-                                const bool has = bits != 0u;
-                                const int r = has ? __builtin_ctz(bits) : 0;
-                                bits &= bits - 1u;
-                                const float v = scratch[slot * 64 + lane];
-                                ++slot;
-                                const int rowloc = 32 * j + (r & 3) + 8 * (r >> 2) + 4 * half;
-                                const u64 key = make_key(v, (int)my_row);
-                                // equal scores: only a key above the show's K-th key can enter its list
-                                const u64 bkey = ((u64)f32_to_ordered(cbound[rowloc]) << 32) | cblo[rowloc];
-                                if (has && key > bkey) {
-                                    const unsigned rowg = (unsigned)col0 + rowloc;
-                                    const unsigned pos = atomicAdd(lcnt, 1u);
-                                    if (pos < (unsigned)a.col_lds) {
-                                        lkey[pos] = key;
-                                        lrowg[pos] = rowg;
-                                    } else {
-                                        col_append(a, rowg, key);  // queue full: straight to the show's buffer
-                                    }
-                                }
-                            }
+                        if (j == NJ - 1 && g == 3) {
+                            if (__any(cqueued > 0)) col_pop();
+                        } else if (__any(cqueued > 4)) {
+                            col_pop();
                         }
                     }
                 }
