@@ -353,6 +353,12 @@ def test_rccl_route_one_rank_group(pkg, device):
             assert z_all.shape[0] == n
             assert torch.equal(top.idx, want.idx) and torch.equal(top.score, want.score)
             assert torch.equal(top.count, want.count)
+        # the symmetric route's collectives (int64 all-gather and all-to-all, int32 max-reduction)
+        for _ in range(2):
+            top, z_all = sharding.sharded_topk_symmetric(x, offsets, scales, sh, k, ms)
+            torch.cuda.synchronize()
+            assert torch.equal(top.idx, want.idx) and torch.equal(top.score, want.score)
+            assert torch.equal(top.count, want.count)
         flag = torch.tensor([3.0], dtype=torch.float64, device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)  # the reduction bench.py uses for its timings
         assert float(flag.item()) == 3.0

@@ -1,11 +1,18 @@
 // MI355X (gfx950 / CDNA4) kernels for the batch similarity + top-K path.
 //
 //   normalize_blocks_kernel   block-wise row L2 normalise + weight        (HBM-bound)
-//   cosine_topk_kernel        Z Z^T on fp32 MFMA fused with per-row top-K (MFMA-bound)
-//   topk_finalize_kernel      merge of the per-column-split partial lists
+//   cosine_tile_kernel        Z Z^T on fp32 MFMA fused with per-row top-K (MFMA-bound), register-staged
+//                             tile loop; also the dense-matrix and the statistics epilogues
+//   cosine_topk_dma_kernel    the same fused top-K with the LDS-DMA tile loop (d % 64 == 0), its work
+//                             cut into equal stretches; symmetric variants feed the lists of the
+//                             column shows too, so that every pair of shows is computed once
+//   col_reduce_kernel         column-side buffers -> one more partial list per show
+//   topk_finalize_kernel      merge of the partial lists of a row
 //   component_scores_kernel   per-block cosines of the kept pairs
+//   query_*_kernel            a few query vectors against the whole catalogue (HBM-bound)
+//   gram_stats_*_kernel       radix-select bookkeeping of the statistics mode
 //
-// The C ABI is declared in include/tvbf.h.  No torch types, no allocation.
+// The C ABI is declared in include/tvbf.h.  No torch types, no device allocation.
 
 #include <hip/hip_runtime.h>
 #include <vector>
