@@ -213,11 +213,12 @@ int tvbf_topk_finish(int64_t nq, int k, int slots, int32_t* out_idx, float* out_
  *
  *   tvbf_colside            col_bound: device, n_total 64-bit keys (the per-row bounds that
  *                           start a top-K workspace: the best known lower bound of each row's
- *                           K-th key, gathered over all shards, indexed by global column); state / state_bytes: device buffer of
+ *                           K-th key, gathered over all shards, indexed by global column; the
+ *                           sweep raises entries of this array as column-side candidates arrive); state / state_bytes: device buffer of
  *                           tvbf_topk_colside_bytes(n_total, cap) bytes that starts with the
  *                           overflow words: word 0 = some buffer overflowed, words 4 .. 4+n_total-1
  *                           = this show's buffer overflowed; cap: candidates kept per show (<= 1024)
- *   tvbf_topk_colside_begin clears the counters and the flag
+ *   tvbf_topk_colside_begin clears the overflow words, the counters and the buffers
  *   tvbf_topk_accumulate_ex tvbf_topk_accumulate_f32 plus, with colside != NULL, the column side
  *                           (d % 64 == 0, k <= 24): a (score, global row) key above col_bound[column]
  *                           is appended to that column's buffer; with
@@ -234,7 +235,7 @@ int tvbf_topk_finish(int64_t nq, int k, int slots, int32_t* out_idx, float* out_
  *                           q_row0) a flagged row merges slots alt_first .. alt_first+alt_slots-1 alone
  */
 typedef struct tvbf_colside {
-    const uint64_t* col_bound;
+    uint64_t* col_bound;
     void* state;
     size_t state_bytes;
     int64_t n_total;

@@ -193,10 +193,11 @@ struct TopkArgs {
     int64_t sh_prefix[MAX_SHARDS + 1];  // tiles of all row blocks before shard v
     // column side of a tile: a score that reaches the bound of its COLUMN's show is appended to
     // that show's buffer -- the pair is then never computed with the roles swapped
-    const u64* col_bound;       // [shows] lower bounds of the K-th keys, by global row
+    u64* col_bound;             // [shows] lower bounds of the K-th keys, by global row (raised by col_refresh_bound)
     unsigned* col_cnt;          // [shows] entries appended (may exceed col_cap: the rest was dropped)
     u64* col_buf;               // [shows][col_cap] keys (score, global row of the QUERY side)
     int col_cap, col_lds;       // entries per show; entries of the workgroup's LDS queue
+    int col_drain;              // queue length at which it is drained between two tiles
     unsigned* overflow;         // [0]: a buffer was full somewhere; [OVF_SHOWS + show]: this show's buffer was
     const unsigned* gate;       // plain sweeps (null: always run): the same layout, indexed by global row --
                                 // only row blocks holding a flagged show are swept
@@ -923,13 +924,76 @@ __host__ __device__ static inline ShardSpans shard_spans(int sym, int v, int V, 
     return sp;
 }
 
-__device__ static inline void col_append(const TopkArgs& a, unsigned rowg, u64 key) {
+constexpr unsigned COL_WINDOW = 256;  // appended entries after which a show's bound is refreshed
+
+// Returns the position the key went to (>= col_cap: dropped).  Entries are written through to
+// device scope so that a refresh on another XCD can see them.
+__device__ static inline unsigned col_append(const TopkArgs& a, unsigned rowg, u64 key) {
     const unsigned p = atomicAdd(a.col_cnt + rowg, 1u);
     if (p < (unsigned)a.col_cap)
-        a.col_buf[(int64_t)rowg * a.col_cap + p] = key;
+        __hip_atomic_store(a.col_buf + (int64_t)rowg * a.col_cap + p, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else {  // dropped: the show's lists are recomputed by the gated plain sweep
         __hip_atomic_store(a.overflow + OVF_SHOWS + rowg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(a.overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return p;
+}
+
+// The column side has no list that adapts as candidates arrive, so a show whose K-th score is
+// shared by thousands of shows (metadata-only matches, identical shows) would take every one of
+// them with a lower index than its current K-th.  Whenever a show's buffer has grown by another
+// COL_WINDOW entries, the wave that appended the last of them ranks that window (the entries
+// already visible; buffers start zeroed and 0 is no key) and raises the show's bound key to the
+// window's K-th best: the K-th best of any set of real candidates is a valid lower bound.
+__device__ static inline void col_refresh_bound(const TopkArgs& a, unsigned rowg, unsigned w0, u64* scr, int lane) {
+    const u64* src = a.col_buf + (int64_t)rowg * a.col_cap + w0;
+    u64 my[4];
+    int rk[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        my[u] = __hip_atomic_load(src + lane + 64 * u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        scr[lane + 64 * u] = my[u];
+        rk[u] = 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma nounroll
+    for (int i = 0; i < (int)COL_WINDOW; i += 4) {
+        u64 o[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o[t] = scr[i + t];  // same address in every lane: LDS broadcast
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rk[u] += o[t] > my[u] ? 1 : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (my[u] != 0ull && rk[u] == a.k - 1)
+            atomicMax(reinterpret_cast<unsigned long long*>(a.col_bound + rowg), (unsigned long long)my[u]);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Drain of the workgroup's queue: every thread appends its share; waves then refresh the bounds
+// of the shows whose buffers completed a window.
+__device__ static inline void col_drain(const TopkArgs& a, const unsigned* lrowg, const u64* lkey, unsigned count,
+                                        int tid, int lane, u64* scr) {
+    for (unsigned base = 0; base < count; base += TOPK_THREADS) {  // uniform trip count
+        const unsigned i = base + tid;
+        unsigned rowg = 0u, p = 0u;
+        bool crossed = false;
+        if (i < count) {
+            rowg = lrowg[i];
+            p = col_append(a, rowg, lkey[i]);
+            crossed = p < (unsigned)a.col_cap && (p + 1u) % COL_WINDOW == 0u;
+        }
+        u64 todo = __ballot(crossed);
+        while (todo) {
+            const int l = (int)__builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            col_refresh_bound(a, __shfl(rowg, l, 64), __shfl(p, l, 64) + 1u - COL_WINDOW, scr, lane);
+        }
     }
 }
 
@@ -1133,9 +1197,9 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
                 cblo[tid] = (uint32_t)cb_key;
             }
             unsigned queued_cols = *lcnt;
-            if (queued_cols >= (unsigned)a.col_lds / 2) {  // uniform: drain the queue into the shows' buffers
+            if (queued_cols >= (unsigned)a.col_drain) {  // uniform: drain the queue into the shows' buffers
                 if (queued_cols > (unsigned)a.col_lds) queued_cols = (unsigned)a.col_lds;
-                for (unsigned i = tid; i < queued_cols; i += TOPK_THREADS) col_append(a, lrowg[i], lkey[i]);
+                col_drain(a, lrowg, lkey, queued_cols, tid, lane, reinterpret_cast<u64*>(scratch));
                 __syncthreads();
                 if (tid == 0) *lcnt = 0u;
             }
@@ -1270,6 +1334,8 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
                 int cqueued = 0;
                 auto col_pop = [&]() {
                     int slot = 0;
+                    bool pend = false;  // this lane's direct append completed a window of a show's buffer
+                    unsigned pend_row = 0u, pend_w0 = 0u;
                     while (__any(cbits != 0ull)) {
                         const bool has = cbits != 0ull;
                         const int idx = has ? __builtin_ctzll(cbits) : 0;
@@ -1286,12 +1352,20 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
                             if (pos < (unsigned)a.col_lds) {
                                 lkey[pos] = key;
                                 lrowg[pos] = rowg;
-                            } else {
-                                col_append(a, rowg, key);  // queue full: straight to the show's buffer
+                            } else {  // queue full: straight to the show's buffer
+                                const unsigned p = col_append(a, rowg, key);
+                                if (p < (unsigned)a.col_cap && (p + 1u) % COL_WINDOW == 0u)
+                                    pend = true, pend_row = rowg, pend_w0 = p + 1u - COL_WINDOW;
                             }
                         }
                     }
                     cqueued = 0;
+                    u64 todo = __ballot(pend);  // the scratch is free again: refresh those shows' bounds
+                    while (todo) {
+                        const int l = (int)__builtin_ctzll(todo);
+                        todo &= todo - 1ull;
+                        col_refresh_bound(a, __shfl(pend_row, l, 64), __shfl(pend_w0, l, 64), reinterpret_cast<u64*>(scratch), lane);
+                    }
                 };
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
@@ -1351,7 +1425,7 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
         __syncthreads();
         unsigned queued_cols = *lcnt;
         if (queued_cols > (unsigned)a.col_lds) queued_cols = (unsigned)a.col_lds;
-        for (unsigned i = tid; i < queued_cols; i += TOPK_THREADS) col_append(a, lrowg[i], lkey[i]);
+        col_drain(a, lrowg, lkey, queued_cols, tid, lane, reinterpret_cast<u64*>(scratch));
     }
 }
 
@@ -1456,7 +1530,7 @@ __global__ __launch_bounds__(64 * COLRED_ROWS) void col_reduce_kernel(const unsi
     for (int i0 = 0; i0 < m; i0 += 64) {
         const int i = i0 + lane;
         const u64 key = i < m ? src[i] : 0ull;
-        const bool keep = i < m && key > thr;
+        const bool keep = i < m && key >= thr;  // the bound may BE one of these keys (col_refresh_bound)
         const u64 mask = __ballot(keep);
         if (keep) b[packed + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = key;
         packed += __builtin_popcountll(mask);
@@ -1472,6 +1546,13 @@ __global__ __launch_bounds__(64 * COLRED_ROWS) void col_reduce_kernel(const unsi
     }
     const u64 empty = sentinel_key(min_similarity);
     for (int i = (packed < k ? packed : k) + lane; i < k; i += 64) dst[i] = empty;
+}
+
+// zero fill of large 16-byte aligned regions (HBM-bound: 16 bytes per thread and step, grid-stride)
+__global__ __launch_bounds__(256) void zero16_kernel(uint4* __restrict__ p, int64_t count16) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count16; i += stride)
+        p[i] = uint4{0u, 0u, 0u, 0u};
 }
 
 __global__ __launch_bounds__(256) void fill_u32_kernel(unsigned* __restrict__ p, int64_t count, unsigned v) {
@@ -1883,7 +1964,9 @@ static int plan_items(TopkArgs* a, int sym, int64_t nq, int shards, int64_t n_al
         const int64_t vset = atoll(e);
         if (vset >= 1) items = vset;
     }
-    if (items > total) items = total;
+    // a list is only as good a filter as the columns it has seen: no stretch shorter than four tiles
+    // (small jobs then run on fewer workgroups)
+    if (items > total / 4) items = total / 4 > 0 ? total / 4 : 1;
     if (max_slots < 1) max_slots = 1;
     for (;;) {
         const int64_t len = total / items;  // shortest stretch
@@ -1921,6 +2004,15 @@ static int colside_queue(int k, int64_t d, size_t* lds_bytes, int* list_cap) {
     if (lds_bytes) *lds_bytes = base + BN * 8 + 16 + (size_t)q * 12;
     if (list_cap) *list_cap = cap;
     return q;
+}
+
+// Queue length at which a workgroup drains its column queue: early enough that the shows' bounds
+// are refreshed while a flood of tied scores is still building up (TVBF_COL_DRAIN: tuning aid).
+static int colside_drain_at(int col_lds) {
+    int at = 128;
+    if (const char* e = getenv("TVBF_COL_DRAIN")) at = atoi(e);
+    if (at > col_lds / 2) at = col_lds / 2;
+    return at < 1 ? 1 : at;
 }
 
 // workspace = [nq bound keys, padded to 16 bytes][slot 0: nq x k keys][slot 1] ...
@@ -2121,12 +2213,13 @@ static int accumulate_impl(const float* Zq, int64_t nq, int64_t q_row0, int64_t 
     if (dma) clear_slots(a.partial, nq, k, slots, (hipStream_t)stream);
     if (cs) {
         char* st = reinterpret_cast<char*>(cs->state);
-        a.col_bound = reinterpret_cast<const u64*>(cs->col_bound);
+        a.col_bound = reinterpret_cast<u64*>(cs->col_bound);
         a.overflow = reinterpret_cast<unsigned*>(st);
         a.col_cnt = reinterpret_cast<unsigned*>(st + cs_cnt_off(cs->n_total));
         a.col_buf = reinterpret_cast<u64*>(st + cs_buf_off(cs->n_total));
         a.col_cap = cs->cap;
         a.col_lds = col_lds;
+        a.col_drain = colside_drain_at(col_lds);
         a.cap = col_list_cap;
     }
 #ifdef TVBF_DIAG_TIMELINE
@@ -2235,6 +2328,7 @@ int tvbf_topk_accumulate_sym_f32(const float* Zq, int64_t nq, int64_t q_row0, in
     a.col_buf = reinterpret_cast<u64*>(cst + cs_buf_off(colside->n_total));
     a.col_cap = colside->cap;
     a.col_lds = col_lds;
+    a.col_drain = colside_drain_at(col_lds);
     u64* lists = reinterpret_cast<u64*>(ws + ws_bound_bytes(nq)) + (size_t)slot0 * nq * k;
     const void* k_diag = reinterpret_cast<const void*>(cosine_topk_dma_kernel<false, SYM_DIAG>);
     const void* k_half = reinterpret_cast<const void*>(cosine_topk_dma_kernel<false, SYM_HALF>);
@@ -2272,7 +2366,15 @@ int tvbf_topk_colside_begin(void* state, size_t state_bytes, int64_t n_total, in
     if (!state || ((uintptr_t)state & 15)) return fail(TVBF_E_BAD_ARG, "null or misaligned state");
     if (!tvbf_topk_colside_bytes(n_total, cap) || state_bytes < tvbf_topk_colside_bytes(n_total, cap))
         return fail(TVBF_E_BAD_SHAPE, "state smaller than tvbf_topk_colside_bytes()");
-    const int64_t words = (int64_t)(cs_buf_off(n_total) / 4);  // flags and counters
+    // flags and counters, then the buffers (an unwritten entry must read as 0 = no key)
+    const int64_t words = (int64_t)(cs_buf_off(n_total) / 4);
+    const int64_t buf16 = (int64_t)((size_t)n_total * cap * 8 / 16);
+    if (buf16 > 0) {
+        int64_t grid = (buf16 + 255) / 256;
+        if (grid > 16384) grid = 16384;
+        hipLaunchKernelGGL(zero16_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<uint4*>(reinterpret_cast<char*>(state) + cs_buf_off(n_total)), buf16);
+    }
     hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<unsigned*>(state), words, 0u);
     HIP_TRY(hipGetLastError());
