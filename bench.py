@@ -307,6 +307,14 @@ def main():
             traffic = json.loads(tf.read_text()).get(key)
         except Exception:
             traffic = None
+    # share of the ordered pairs the sweeps really compute (1 for the plain sweep): with V shards the
+    # own-columns sweeps take 1/V (both orders), every pair of different shards is computed once
+    share = 1.0
+    if symmetric and world == 1:
+        v = max(2, min(32, ((nq + 127) // 128) // 8))
+        share = 1.0 / v + (v - 1) / (2.0 * v)
+    elif symmetric:
+        share = None  # per rank: own block symmetric + (world - 1) / 2 foreign blocks; see the design notes
     line = {
         "metric": "show-pairs/sec (all-pairs cosine + per-row top-K)",
         "value": pairs / elapsed,
@@ -335,7 +343,11 @@ def main():
                                 "route; HIP events span the whole call: fills, column-buffer reduction, list merge)"
                                 if symmetric else
                                 "cosine_topk_dma_kernel<false, 0> (HIP events also span the 4 us bound fill and the "
-                                "0.3 ms list merge of the same call)"), "kernel_ms": kernel_avg_ms},
+                                "0.3 ms list merge of the same call)"), "kernel_ms": kernel_avg_ms,
+                     "pairs_computed_share": share,
+                     "executed_frac": None if share is None else achieved * share / FP32_MFMA_PEAK_TFLOPS,
+                     "note": "achieved and frac count 2*D flops for every ordered pair (the work the path is "
+                             "specified by); executed_frac = the flops really executed over the peak"},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         x_host = x[:nq].cpu().numpy()
