@@ -51,7 +51,7 @@ out = {
     "derived": {
         "kernel_ms_rocprof_avg": round(ms, 3), "kernel_ms_each": per_kernel,
         "TFLOPs_of_2N2D": round(2 * 1e5 * 1e5 * 1024 / (ms * 1e-3) / 1e12, 2),
-        "TFLOPs_executed": round(mfma * 64 * 64 * 2 / (ms * 1e-3) / 1e12, 2),
+        "TFLOPs_executed": round(mfma * 4096 / (ms * 1e-3) / 1e12, 2),
         "share_of_all_ordered_pairs_computed": round(mfma / (782 * 782 * 4 * 2048), 4),
         "effective_clock_GHz": round(cyc / (ms * 1e-3) / 1e9, 3),
         "mfma_pipe_busy_frac": round(sq1["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cyc), 4),
