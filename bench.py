@@ -185,8 +185,11 @@ def main():
     ws_bytes = int(native.load().tvbf_topk_workspace_bytes_for_slots(max(nq, 1), args.k, slots))
     workspace = torch.empty((ws_bytes + 15) // 16 * 2, dtype=torch.int64, device=dev)
     sym_bytes = engine.symmetric_workspace_bytes(args.n, ld, args.k) if args.sweep != "plain" else 0
+    if world > 1 and not sharding.symmetric_route_fits(world, args.k, ld):
+        sym_bytes = 0
     if args.sweep == "symmetric" and not sym_bytes:
-        raise SystemExit("--sweep symmetric: row length a multiple of 64, k <= 24 and >= 256 shows only")
+        raise SystemExit("--sweep symmetric: row length a multiple of 64, more than 1920 shows, and for several "
+                         "GPUs a K small enough that one merge takes all lists")
     symmetric = sym_bytes > 0
     side = None
     if symmetric and world == 1:

@@ -153,8 +153,7 @@ int tvbf_cosine_topk_f32(const float* Zq, int64_t nq, int64_t q_row0, const floa
  * matrix is symmetric bit for bit and the result equals tvbf_cosine_topk_f32's exactly; only
  * about half of it (plus 1/16 for seeding the bounds) is computed.
  *
- *   d           multiple of 64;  k <= 24 (the lists and the column queue share LDS);
- *               n large enough for two shards of 128-row blocks
+ *   d           multiple of 64;  n at least 16 blocks of 128 rows (more than 1920 shows)
  *   workspace   >= tvbf_cosine_topk_sym_workspace_bytes(n, d, k) bytes, which returns 0 when
  *               the shape is not taken (call tvbf_cosine_topk_f32 then)
  * Every show has a buffer of 1024 column-side candidates; should one overflow, the show is
@@ -188,8 +187,8 @@ int tvbf_cosine_topk_sym_inspect(const void* workspace, int64_t n, int64_t d, in
  *                          slots slot0, slot0+1, ... (at most max_slots of them)
  *   tvbf_topk_finish       merges slots 0..slots-1 into out_idx / out_score / out_count
  *
- * All calls of one sequence use the same nq, k, min_similarity, workspace and stream.  The total
- * number of slots may not exceed tvbf_topk_max_slots(k); a workspace of
+ * All calls of one sequence use the same nq, k, min_similarity, workspace and stream.  One merge
+ * takes at most tvbf_topk_max_slots(k) lists; a workspace of
  * tvbf_topk_workspace_bytes_for_slots(nq, k, slots) bytes holds `slots` of them.
  * tvbf_cosine_topk_f32 is begin + one accumulate over all n columns + finish.
  */
@@ -220,7 +219,7 @@ int tvbf_topk_finish(int64_t nq, int k, int slots, int32_t* out_idx, float* out_
  *                           = this show's buffer overflowed; cap: candidates kept per show (<= 1024)
  *   tvbf_topk_colside_begin clears the overflow words, the counters and the buffers
  *   tvbf_topk_accumulate_ex tvbf_topk_accumulate_f32 plus, with colside != NULL, the column side
- *                           (d % 64 == 0, k <= 24): a (score, global row) key above col_bound[column]
+ *                           (d % 64 == 0): a (score, global row) key above col_bound[column]
  *                           is appended to that column's buffer; with
  *                           gate != NULL (device, the overflow words of a column-side state,
  *                           max-reduced over the shards) only the 128-row blocks that hold a
@@ -247,7 +246,7 @@ typedef struct tvbf_colside {
  * (columns q_row0 .. q_row0+nq-1 = the rows of Zq), every pair computed once, inside an
  * incremental sequence.  Uses the column-side state at the shard's global rows (col_bound of
  * the descriptor is not read: the bounds are the workspace's own) and writes *slots_used
- * lists.  Needs d % 64 == 0, k <= 24, nq >= 2048, max_slots >= 3.
+ * lists.  Needs d % 64 == 0, nq > 1920 (16 blocks of 128 rows), max_slots >= 3.
  */
 int tvbf_topk_accumulate_sym_f32(const float* Zq, int64_t nq, int64_t q_row0, int64_t d, int64_t ld, int k,
                                  float min_similarity, int exclude_self, void* workspace,

@@ -1000,8 +1000,6 @@ __device__ static inline void col_drain(const TopkArgs& a, const unsigned* lrowg
 template <bool LIST_GLOBAL, int SYM = SYM_OFF, bool COLSIDE = (SYM == SYM_HALF)>
 __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkArgs a) {
     static_assert(BK == 32 && BM == 128 && BN == 128, "the DMA tile loop is written for 128 x 128 x 32 tiles");
-    static_assert(SYM == SYM_OFF || !LIST_GLOBAL, "the symmetric sweeps keep their lists in LDS");
-    static_assert(!COLSIDE || !LIST_GLOBAL, "the column queue shares LDS with the lists");
     if (SYM == SYM_OFF && !COLSIDE && a.gate && __hip_atomic_load(a.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
     __shared__ __attribute__((aligned(16))) float tileC0[BN * BK];
     __shared__ __attribute__((aligned(16))) float tileC1[BN * BK];
@@ -1011,8 +1009,8 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
     unsigned* cnt_all = reinterpret_cast<unsigned*>(mkey_all + BM);        // [BM]
     float* scratch_all = reinterpret_cast<float*>(cnt_all + BM);           // [4][DMA_SLOTS * 64]
     u64* merge_scr = reinterpret_cast<u64*>(scratch_all + 4 * DMA_SLOTS * 64);  // [4][k + cap], global lists only
-    // column side (same place as merge_scr, which only the global lists use)
-    float* cbound = scratch_all + 4 * DMA_SLOTS * 64;                      // [BN] bound keys of the tile's column shows: score parts
+    // column side, behind the merge scratch (which only the global lists have)
+    float* cbound = reinterpret_cast<float*>(merge_scr + (LIST_GLOBAL ? (size_t)4 * (a.k + a.cap) : 0));  // [BN] bound keys of the tile's column shows: score parts
     unsigned* cblo = reinterpret_cast<unsigned*>(cbound + BN);             // [BN] ... and column words
     unsigned* lcnt = cblo + BN;                                            // entries queued (4 words reserved)
     u64* lkey = reinterpret_cast<u64*>(lcnt + 4);                          // [col_lds]
@@ -1986,16 +1984,23 @@ static void clear_slots(u64* lists, int64_t nq, int k, int slots, hipStream_t st
                        reinterpret_cast<unsigned*>(lists), words, 0u);
 }
 
-// LDS of the sweeps with a column side: the lists (at most 34 entries per row, so that the queue
-// fits for every k <= 24), the tile's column bounds and a queue of (key, show) entries in what is
-// left of half a CU's LDS.  Returns the queue entries (0: does not fit), the dynamic LDS bytes of
-// the kernel and the list capacity to launch with.
+// LDS of the sweeps with a column side: the lists (LDS lists capped at 34 entries per row, staging
+// buffers of the global lists at 28, so that the queue fits for every k), the tile's column
+// bounds and a queue of (key, show) entries in what is left of half a CU's LDS.  Returns the queue
+// entries (0: does not fit), the dynamic LDS bytes of the kernel and the list capacity to launch with.
 static int colside_queue(int k, int64_t d, size_t* lds_bytes, int* list_cap) {
-    if (!topk_use_dma(d) || topk_list_global(k)) return 0;
+    if (!topk_use_dma(d)) return 0;
+    const bool global_lists = topk_list_global(k);
     int cap = topk_cap(k, d);
-    if (cap > 34) cap = 34;
-    if (cap < k + 4) return 0;
-    const size_t base = (size_t)BM * cap * 8 + (size_t)BM * 8 + (size_t)BM * 4 + (size_t)4 * DMA_SLOTS * 64 * sizeof(float);
+    if (global_lists) {
+        if (cap > 28) cap = 28;
+    } else {
+        if (cap > 34) cap = 34;
+        if (cap < k + 4) return 0;
+    }
+    const size_t merge_scratch = global_lists ? (size_t)4 * (k + cap) * 8 : 0;
+    const size_t base = (size_t)BM * cap * 8 + (size_t)BM * 8 + (size_t)BM * 4 +
+                        (size_t)4 * DMA_SLOTS * 64 * sizeof(float) + merge_scratch;
     const size_t fixed = base + topk_static_lds_bytes(d) + BN * 8 + 16;  // score and column words of a tile's column bounds
     const size_t room = fixed < 80 * 1024 ? 80 * 1024 - fixed : 0;
     int q = (int)(room / 12) / 64 * 64;
@@ -2121,8 +2126,8 @@ static int validate_accumulate(const float* Zq, int64_t nq, int64_t q_row0, int6
         return fail(TVBF_E_BAD_SHAPE, "Z must be 16-byte aligned");
     if (ld > (INT32_MAX / 4) / (BM + BN)) return fail(TVBF_E_BAD_SHAPE, "ld too large");
     if (min_similarity != min_similarity) return fail(TVBF_E_BAD_ARG, "min_similarity is NaN");
-    if (slot0 < 0 || max_slots < 1 || slot0 + max_slots > max_merge_slots(k))
-        return fail(TVBF_E_BAD_ARG, "slot range must lie in [0, %d)", max_merge_slots(k));
+    // slots are limited by the workspace only; the merge takes at most max_merge_slots(k) lists at once
+    if (slot0 < 0 || max_slots < 1) return fail(TVBF_E_BAD_ARG, "bad slot range");
     return TVBF_OK;
 }
 
@@ -2168,7 +2173,7 @@ static int accumulate_impl(const float* Zq, int64_t nq, int64_t q_row0, int64_t 
             return fail(TVBF_E_BAD_SHAPE, "column side: column ranges must lie inside [0, n_total)");
         col_lds = colside_queue(k, d, &p.lds_bytes, &col_list_cap);
         if (!col_lds)
-            return fail(TVBF_E_BAD_SHAPE, "the column side needs d %% 64 == 0 and k <= 24");
+            return fail(TVBF_E_BAD_SHAPE, "the column side needs d %% 64 == 0");
         if (gate) return fail(TVBF_E_BAD_ARG, "a gated sweep has no column side");
     }
     const bool list_global = topk_list_global(k), dma = topk_use_dma(d);
@@ -2185,7 +2190,8 @@ static int accumulate_impl(const float* Zq, int64_t nq, int64_t q_row0, int64_t 
     if (workspace_bytes < need) return fail(TVBF_E_BAD_SHAPE, "workspace must be >= %zu bytes", need);
     if (grid > INT32_MAX) return fail(TVBF_E_BAD_ARG, "too many workgroups");
     const void* kernel =
-        cs  ? reinterpret_cast<const void*>(cosine_topk_dma_kernel<false, SYM_OFF, true>)
+        cs  ? (list_global ? reinterpret_cast<const void*>(cosine_topk_dma_kernel<true, SYM_OFF, true>)
+                           : reinterpret_cast<const void*>(cosine_topk_dma_kernel<false, SYM_OFF, true>))
         : dma ? (list_global ? reinterpret_cast<const void*>(cosine_topk_dma_kernel<true>)
                              : reinterpret_cast<const void*>(cosine_topk_dma_kernel<false>))
               : (list_global ? reinterpret_cast<const void*>(cosine_tile_kernel<MODE_TOPK_G>)
@@ -2225,7 +2231,10 @@ static int accumulate_impl(const float* Zq, int64_t nq, int64_t q_row0, int64_t 
 #ifdef TVBF_DIAG_TIMELINE
     if (const char* e = getenv("TVBF_DIAG_BUF")) a.gram = reinterpret_cast<float*>(strtoull(e, nullptr, 0));
 #endif
-    if (cs)
+    if (cs && list_global)
+        hipLaunchKernelGGL((cosine_topk_dma_kernel<true, SYM_OFF, true>), dim3((unsigned)grid), dim3(TOPK_THREADS),
+                           p.lds_bytes, (hipStream_t)stream, a);
+    else if (cs)
         hipLaunchKernelGGL((cosine_topk_dma_kernel<false, SYM_OFF, true>), dim3((unsigned)grid), dim3(TOPK_THREADS),
                            p.lds_bytes, (hipStream_t)stream, a);
     else if (dma && list_global)
@@ -2289,7 +2298,7 @@ int tvbf_topk_accumulate_sym_f32(const float* Zq, int64_t nq, int64_t q_row0, in
     const int row_blocks = (int)((nq + BM - 1) / BM);
     int shards = sym_shards(row_blocks);
     if (!col_lds || shards < 2)
-        return fail(TVBF_E_BAD_SHAPE, "the symmetric sweep needs d %% 64 == 0, k <= 24 and at least 16 row blocks");
+        return fail(TVBF_E_BAD_SHAPE, "the symmetric sweep needs d %% 64 == 0 and at least 16 row blocks");
     if (shards > MAX_SHARDS) shards = MAX_SHARDS;
     const int cus = device_cus();
     int budget = max_slots - 1;  // one slot is the reduced column side
@@ -2330,13 +2339,19 @@ int tvbf_topk_accumulate_sym_f32(const float* Zq, int64_t nq, int64_t q_row0, in
     a.col_lds = col_lds;
     a.col_drain = colside_drain_at(col_lds);
     u64* lists = reinterpret_cast<u64*>(ws + ws_bound_bytes(nq)) + (size_t)slot0 * nq * k;
-    const void* k_diag = reinterpret_cast<const void*>(cosine_topk_dma_kernel<false, SYM_DIAG>);
-    const void* k_half = reinterpret_cast<const void*>(cosine_topk_dma_kernel<false, SYM_HALF>);
+    const bool list_global = topk_list_global(k);
+    const void* k_diag = list_global ? reinterpret_cast<const void*>(cosine_topk_dma_kernel<true, SYM_DIAG>)
+                                     : reinterpret_cast<const void*>(cosine_topk_dma_kernel<false, SYM_DIAG>);
+    const void* k_half = list_global ? reinterpret_cast<const void*>(cosine_topk_dma_kernel<true, SYM_HALF>)
+                                     : reinterpret_cast<const void*>(cosine_topk_dma_kernel<false, SYM_HALF>);
     HIP_TRY(hipFuncSetAttribute(k_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag));
     HIP_TRY(hipFuncSetAttribute(k_half, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_half));
     clear_slots(lists, nq, k, s_diag + s_half, st);
     a.partial = lists;
-    if (a.items > 0)
+    if (a.items > 0 && list_global)
+        hipLaunchKernelGGL((cosine_topk_dma_kernel<true, SYM_DIAG>), dim3((unsigned)a.items), dim3(TOPK_THREADS),
+                           lds_diag, st, a);
+    else if (a.items > 0)
         hipLaunchKernelGGL((cosine_topk_dma_kernel<false, SYM_DIAG>), dim3((unsigned)a.items), dim3(TOPK_THREADS),
                            lds_diag, st, a);
     // the half sweep: same arguments, its own shard table, the lists capped for the column queue
@@ -2346,7 +2361,10 @@ int tvbf_topk_accumulate_sym_f32(const float* Zq, int64_t nq, int64_t q_row0, in
     memcpy(a.sh_prefix, ah.sh_prefix, sizeof(a.sh_prefix));
     a.partial = lists + (size_t)s_diag * nq * k;
     a.cap = half_cap;
-    if (a.items > 0)
+    if (a.items > 0 && list_global)
+        hipLaunchKernelGGL((cosine_topk_dma_kernel<true, SYM_HALF>), dim3((unsigned)a.items), dim3(TOPK_THREADS),
+                           lds_half, st, a);
+    else if (a.items > 0)
         hipLaunchKernelGGL((cosine_topk_dma_kernel<false, SYM_HALF>), dim3((unsigned)a.items), dim3(TOPK_THREADS),
                            lds_half, st, a);
     hipLaunchKernelGGL(col_reduce_kernel, dim3((unsigned)((nq + COLRED_ROWS - 1) / COLRED_ROWS)), dim3(64 * COLRED_ROWS),
@@ -2531,7 +2549,7 @@ int tvbf_cosine_topk_sym_f32(const float* Z, int64_t n, int64_t d, int64_t ld, i
     if (rc) return rc;
     const SymPlan sp = make_sym_plan(n, d, k);
     if (!sp.ok)
-        return fail(TVBF_E_BAD_SHAPE, "the symmetric sweep needs d %% 64 == 0, k <= 24 and at least 16 blocks of 128 rows");
+        return fail(TVBF_E_BAD_SHAPE, "the symmetric sweep needs d %% 64 == 0 and at least 16 blocks of 128 rows");
     if (workspace_bytes < sp.bytes) return fail(TVBF_E_BAD_SHAPE, "workspace must be >= %zu bytes", sp.bytes);
     // the pieces of the incremental interface in a row: bounds, own block symmetric (which here is
     // the whole catalogue), the plain sweep behind the overflow gate, the merge

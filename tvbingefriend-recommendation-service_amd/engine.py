@@ -208,7 +208,7 @@ def cosine_topk(z_all: torch.Tensor, k: int, min_similarity: float, *, q_row0: i
 
 def symmetric_workspace_bytes(n: int, ld: int, k: int) -> int:
     """Workspace of :func:`cosine_topk_symmetric`; 0 when that route does not take the shape
-    (row length not a multiple of 64, k above 24, fewer than two shards of rows)."""
+    (row length not a multiple of 64, fewer than 16 blocks of 128 rows)."""
     return int(native.load().tvbf_cosine_topk_sym_workspace_bytes(int(n), int(ld), int(k)))
 
 
@@ -465,7 +465,7 @@ class TopkSession:
         self.min_similarity, self.exclude_self = float(min_similarity), bool(exclude_self)
         self.ld = z_q.shape[1]
         self.dev = z_q.device
-        self.slots = min(int(slots), int(self.lib.tvbf_topk_max_slots(k)))
+        self.slots = int(slots)  # what the workspace holds; one merge takes at most tvbf_topk_max_slots(k) lists
         need = int(self.lib.tvbf_topk_workspace_bytes_for_slots(max(self.nq, 1), k, self.slots))
         if workspace is None:
             workspace = torch.empty((need + 15) // 16 * 2, dtype=torch.int64, device=self.dev)
@@ -500,7 +500,7 @@ class TopkSession:
     def accumulate_own_symmetric(self, side: "ColumnSide", max_slots: int = 16) -> int:
         """The block of these rows against their own columns (z_q is both), every pair once; the
         column side goes through ``side`` at the rows' global indices.  Raises when the shape is
-        not taken (row length not a multiple of 64, k > 24, fewer than 2048 rows)."""
+        not taken (row length not a multiple of 64, fewer than 16 blocks of 128 rows)."""
         import ctypes
 
         if self.nq == 0:

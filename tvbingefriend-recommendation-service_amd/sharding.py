@@ -273,6 +273,14 @@ class SymmetricShardJob:
                                    slots=self.normal_slots)
 
 
+def symmetric_route_fits(world: int, k: int, ld: int) -> bool:
+    """Whether sharded_topk_symmetric takes the shape: LDS-DMA rows and a merge wide enough for
+    about 32 own lists (own block, half sweep, second sweep of an upper partner) plus `world` received."""
+    from . import native
+
+    return ld % 64 == 0 and int(native.load().tvbf_topk_max_slots(int(k))) >= 32 + world
+
+
 def _via_host(t: torch.Tensor, group) -> bool:
     return t.is_cuda and dist.get_backend(group) == "gloo"  # gloo: CPU tensors only
 
@@ -324,7 +332,8 @@ def sharded_topk_symmetric(x_shard: torch.Tensor, offsets, scales, shard: Shard,
     all-gather of Z (asynchronous) -> own block -> all-gather of the per-row bounds -> blocks of the
     cyclically following half of the shards, rows and columns fed -> all-to-all of the column-side
     lists (world x per_rank x k keys) -> merge.  Same lists as sharded_topk, bit for bit.
-    Needs a row length that is a multiple of 64 and k <= 24 (the engine raises otherwise)."""
+    Needs a row length that is a multiple of 64 (the engine raises otherwise) and a K for which one
+    merge can take the rank's own lists plus one per rank: symmetric_route_fits()."""
     if normalize_fn is None:
         from . import engine
 
