@@ -270,6 +270,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    if symmetric and world > 1:
+        # untimed priming step of the symmetric sharded route (it uses collectives the plain route
+        # does not: int64 all-gather and all-to-all, int32 max-reduction); if it raises, all ranks
+        # go on with the plain sharded route together
+        ok = 1.0
+        try:
+            step(False)
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            ok = 0.0
+            print(f"[rank {rank}] symmetric sharded route failed ({e!r}); falling back to the plain route",
+                  file=sys.stderr, flush=True)
+        if -max_over_ranks(-ok) < 1.0:
+            symmetric = False
     for _ in range(args.warmup):
         step(False)
     barrier()

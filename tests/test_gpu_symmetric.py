@@ -340,8 +340,9 @@ def test_symmetric_sharded_job_large_k(pkg, device):
 
     z, _, _ = _z_hybrid(device, 9100, seed=5)
     k = 50
-    assert sharding.symmetric_route_fits(4, k, z.shape[1]) and not sharding.symmetric_route_fits(8, 100, z.shape[1])
+    assert sharding.symmetric_route_fits(4, k, z.shape[1]) and sharding.symmetric_route_fits(8, k, z.shape[1])
+    assert not sharding.symmetric_route_fits(8, 100, z.shape[1])
     plain = engine.cosine_topk(z, k, 0.1)
-    for world in (2, 4):
+    for world in (2, 4, 8):
         got, _ = _lockstep_ranks(device, z, 9100, world, k, 0.1)
         _assert_same(got, plain, f"k=50 world={world}")

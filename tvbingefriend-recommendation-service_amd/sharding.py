@@ -198,6 +198,9 @@ class SymmetricShardJob:
         if colside is not None:
             self.side.begin()
         self.normal_slots = 0
+        self.per_sweep = _sweep_slots(shard.world, k)
+        if self.per_sweep < 6:
+            raise ValueError("k too large for the symmetric sharded route with this many ranks: use sharded_topk")
         # upper partner: second sweep over the rows [h0, rows) of this shard
         self.sub, self.h0 = None, 0
         pt = partner(shard.world, shard.rank)
@@ -210,9 +213,9 @@ class SymmetricShardJob:
     def phase_own(self):
         own, _, _ = column_pieces(self.shard)
         if self.shard.rows >= 2048:   # large enough for the symmetric sweep inside the block
-            self.session.accumulate_own_symmetric(self.side)
+            self.session.accumulate_own_symmetric(self.side, max_slots=self.per_sweep)
         else:
-            self.session.accumulate((self.z_shard, own[1], own[0]))
+            self.session.accumulate((self.z_shard, own[1], own[0]), max_slots=self.per_sweep)
 
     def own_bounds(self) -> torch.Tensor:
         b = torch.full((self.shard.per_rank,), PAD_BOUND, dtype=torch.int64, device=self.dev)
@@ -222,7 +225,7 @@ class SymmetricShardJob:
 
     def phase_half(self, z_all: torch.Tensor, bounds_all: torch.Tensor):
         a, b = half_pieces(self.shard)
-        self.session.accumulate((z_all[a[0]:], a[1], a[0]), (z_all[b[0]:], b[1], b[0]),
+        self.session.accumulate((z_all[a[0]:], a[1], a[0]), (z_all[b[0]:], b[1], b[0]), max_slots=self.per_sweep,
                                 colside=(self.side, bounds_all))
         self.normal_slots = self.session.used
         if self.sub is not None:
@@ -231,7 +234,7 @@ class SymmetricShardJob:
             c0 = min(pt * sh.per_rank, sh.n)
             cols = min((pt + 1) * sh.per_rank, sh.n) - c0
             self.sub.bounds().copy_(self.session.bounds()[self.h0:])  # start from what the own block found
-            self.sub.accumulate((z_all[c0:], cols, c0), colside=(self.side, bounds_all))
+            self.sub.accumulate((z_all[c0:], cols, c0), max_slots=self.per_sweep, colside=(self.side, bounds_all))
 
     def lists_for_peers(self, bounds_all: torch.Tensor) -> torch.Tensor:
         sh = self.shard
@@ -274,11 +277,17 @@ class SymmetricShardJob:
 
 
 def symmetric_route_fits(world: int, k: int, ld: int) -> bool:
-    """Whether sharded_topk_symmetric takes the shape: LDS-DMA rows and a merge wide enough for
-    about 32 own lists (own block, half sweep, second sweep of an upper partner) plus `world` received."""
+    """Whether sharded_topk_symmetric takes the shape: LDS-DMA rows and a merge wide enough for the
+    lists of three sweeps (own block, half sweep, second sweep of an upper partner; at least six
+    each) plus the `world` received ones."""
+    return ld % 64 == 0 and _sweep_slots(world, k) >= 6
+
+
+def _sweep_slots(world: int, k: int) -> int:
+    """List slots each of a rank's three sweeps may use so that one merge takes them all."""
     from . import native
 
-    return ld % 64 == 0 and int(native.load().tvbf_topk_max_slots(int(k))) >= 32 + world
+    return min(16, (int(native.load().tvbf_topk_max_slots(int(k))) - world) // 3)
 
 
 def _via_host(t: torch.Tensor, group) -> bool:
