@@ -127,8 +127,9 @@ __global__ __launch_bounds__(256) void normalize_blocks_kernel(const float* __re
 // block of scores as four 32x32 MFMA tiles computed TRANSPOSED: the MFMA "A"
 // operand is the column-show fragment and the "B" operand the query fragment,
 // so lane l ends up holding query row (l & 31) in all of its 64 accumulator
-// registers.  The running K-th best score of that row is one register, and a
-// tile is rejected with 32 v_max3 + 1 compare.
+// registers.  The running K-th best score of that row is one register: every
+// accumulator is compared with it once, and only the few that pass (about
+// eleven per wave and tile) are queued and looked at again.
 //
 // v_mfma_f32_32x32x2_f32 takes k = (lane >> 5) of a 2-deep step from each
 // lane; one ds_read_b128 supplies four consecutive steps: step i of read t
