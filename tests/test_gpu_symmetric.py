@@ -346,3 +346,40 @@ def test_symmetric_sharded_job_large_k(pkg, device):
     for world in (2, 4, 8):
         got, _ = _lockstep_ranks(device, z, 9100, world, k, 0.1)
         _assert_same(got, plain, f"k=50 world={world}")
+
+
+def test_topk_calls_can_be_captured_in_a_graph(pkg, device):
+    """The library allocates nothing and clears memory with kernels, so a caller can capture a
+    whole top-K call in a HIP graph: every replay (with unrelated eager work and synchronisations
+    in between) must reproduce the eager lists, for the symmetric and for the plain call."""
+    import torch
+
+    from tvbingefriend_recommendation_service_amd import engine
+
+    n, d, k = 4096, 128, 20
+    z = engine.normalize_blocks(torch.from_numpy(dense_gaussian(n, d, seed=8)).to(device), [0, d], [1.0])
+    ref = engine.cosine_topk(z, k, -1.0)
+    torch.cuda.synchronize()
+    nb = engine.symmetric_workspace_bytes(n, d, k)
+    ws = torch.empty((nb + 15) // 16 * 2, dtype=torch.int64, device=device)  # also large enough for the plain call
+    out = engine.TopK(torch.empty((n, k), dtype=torch.int32, device=device), torch.empty((n, k), device=device),
+                      torch.empty((n,), dtype=torch.int32, device=device))
+    calls = {"symmetric": lambda: engine.cosine_topk_symmetric(z, k, -1.0, workspace=ws, out=out),
+             "plain": lambda: engine.cosine_topk(z, k, -1.0, workspace=ws, out=out)}
+    side = torch.cuda.Stream()
+    for name, call in calls.items():
+        with torch.cuda.stream(side):
+            call()  # first call outside the capture (sets kernel attributes)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            call()
+        for rep in range(3):
+            out.idx.fill_(-7)
+            out.score.zero_()
+            out.count.zero_()
+            _ = torch.randn((128, 128), device=device) @ torch.randn((128, 128), device=device)
+            torch.cuda.synchronize()
+            graph.replay()
+            torch.cuda.synchronize()
+            _assert_same(out, ref, f"{name} replay {rep}")
