@@ -315,3 +315,24 @@ def test_both_tile_loops_give_identical_lists(pkg, device, monkeypatch, n, d, k,
         assert np.array_equal(a_, b_)
     h, _ = _oracle_h(blocks, weights)
     check_topk_against_scores(h, 0, k, ms, *results["dma"], what=f"tile loops {n}x{d}")
+
+
+def test_session_budgets_respect_the_merge_limit(pkg, device):
+    """K = 100: one merge takes 20 lists, so the sweeps of a session share that many slots; three
+    column pieces must still merge into the lists of one sweep."""
+    import torch
+
+    from tvbingefriend_recommendation_service_amd import engine
+
+    n, d, k = 6000, 128, 100
+    z = engine.normalize_blocks(torch.from_numpy(dense_gaussian(n, d, seed=17)).to(device), [0, d], [1.0])
+    full = engine.cosine_topk(z, k, -1.0)
+    ses = engine.TopkSession(z, n, 0, k, -1.0, slots=64)
+    assert ses.max_lists == 20
+    for lo, hi in ((0, 2500), (2500, 4000), (4000, n)):
+        ses.accumulate((z[lo:], hi - lo, lo))
+    assert ses.used <= ses.max_lists
+    top = ses.finish()
+    torch.cuda.synchronize()
+    for f in ("idx", "score", "count"):
+        assert torch.equal(getattr(top, f), getattr(full, f)), f

@@ -465,7 +465,9 @@ class TopkSession:
         self.min_similarity, self.exclude_self = float(min_similarity), bool(exclude_self)
         self.ld = z_q.shape[1]
         self.dev = z_q.device
-        self.slots = int(slots)  # what the workspace holds; one merge takes at most tvbf_topk_max_slots(k) lists
+        self.slots = int(slots)  # what the workspace holds
+        self.max_lists = int(self.lib.tvbf_topk_max_slots(k))  # what one merge takes
+        self.gated_used = 0
         need = int(self.lib.tvbf_topk_workspace_bytes_for_slots(max(self.nq, 1), k, self.slots))
         if workspace is None:
             workspace = torch.empty((need + 15) // 16 * 2, dtype=torch.int64, device=self.dev)
@@ -505,7 +507,7 @@ class TopkSession:
 
         if self.nq == 0:
             return 0
-        budget = min(max_slots, self.slots - self.used)
+        budget = min(max_slots, self.slots - self.used, self.max_lists - self.used)
         used = ctypes.c_int(0)
         st = native.ColSide(None, side.state.data_ptr(), side.bytes, side.n_total, side.cap)
         with torch.cuda.device(self.dev):
@@ -531,9 +533,12 @@ class TopkSession:
         pb, nb, cb, keep_b = self._range(range_b, self.ld)
         if na + nb == 0 or self.nq == 0:
             return 0
-        budget = min(max_slots, self.slots - self.used)
+        # the lists of the ordinary sweeps are merged together, those of the gated sweeps instead of them
+        merged_so_far = self.gated_used if gate is not None else self.used
+        budget = min(max_slots, self.slots - self.used, self.max_lists - merged_so_far)
         if budget < 1:
-            raise ValueError("no partial-list slots left: create the session with more slots")
+            raise ValueError("no partial-list slots left: create the session with more slots, or K is too large "
+                             "for this many sweeps")
         import ctypes
 
         used = ctypes.c_int(0)
@@ -552,6 +557,8 @@ class TopkSession:
                 self.used, budget, ctypes.byref(used), cs_ref, gate_ptr, _stream_ptr())
         native.check(rc, "tvbf_topk_accumulate_ex_f32")
         self.used += used.value
+        if gate is not None:
+            self.gated_used += used.value
         return used.value
 
     def finish(self, out: TopK | None = None, *, extra: torch.Tensor | None = None, gate=None,
