@@ -1927,8 +1927,11 @@ static int sym_shards(int row_blocks) {
 // list slots the launch writes per row (the largest number of workgroup stretches that can cut
 // one row block), or 0 when there is nothing to sweep.  `sym` = SYM_OFF: one "shard" of all row
 // blocks with col_tiles tiles each; otherwise `shards` shards whose tiles follow from shard_spans().
+// `gated`: a sweep that skips every row block without a flagged show.  Its few busy row blocks are
+// cut into about twelve stretches each, so that many workgroups share one block (with the usual
+// stretches a single flagged show would keep one workgroup busy for a whole row-block sweep).
 static int plan_items(TopkArgs* a, int sym, int64_t nq, int shards, int64_t n_all, int col_tiles, int cus,
-                      int wg_per_cu, int max_slots) {
+                      int wg_per_cu, int max_slots, bool gated = false) {
     const int RB = (int)((nq + BM - 1) / BM);
     a->row_blocks = RB;
     int t_max = 0;
@@ -1959,6 +1962,7 @@ static int plan_items(TopkArgs* a, int sym, int64_t nq, int shards, int64_t n_al
         return 0;
     }
     int64_t items = (int64_t)cus * wg_per_cu;  // every workgroup resident at once, all with the same amount of work
+    if (gated && (int64_t)RB * 12 > items) items = (int64_t)RB * 12;
     if (const char* e = getenv("TVBF_ITEMS")) {  // tuning aid; any value gives the same result
         const int64_t vset = atoll(e);
         if (vset >= 1) items = vset;
@@ -2184,7 +2188,7 @@ static int accumulate_impl(const float* Zq, int64_t nq, int64_t q_row0, int64_t 
     int slots = p.splits;
     int64_t grid = (int64_t)p.row_blocks * p.splits;
     if (dma) {  // equal stretches of the line of tiles, one per resident workgroup
-        slots = plan_items(&a, SYM_OFF, nq, 1, 0, tiles, device_cus(), p.wg_per_cu, max_slots);
+        slots = plan_items(&a, SYM_OFF, nq, 1, 0, tiles, device_cus(), p.wg_per_cu, max_slots, gate != nullptr);
         grid = a.items;
     }
     const size_t need = ws_bound_bytes(nq) + (size_t)(slot0 + slots) * ws_slot_bytes(nq, k);
@@ -2522,7 +2526,7 @@ static SymPlan make_sym_plan(int64_t n, int64_t d, int k) {
     const int s_diag = plan_items(&a, SYM_DIAG, n, shards, n, 0, cus, 2, (slots - 1) / 2);
     const int s_half = plan_items(&a, SYM_HALF, n, shards, n, 0, cus, 2, slots - 1 - s_diag);
     sp.s_sym = s_diag + s_half + 1;
-    sp.s_full = plan_items(&a, SYM_OFF, n, 1, 0, tiles_of(n), cus, 2, slots);
+    sp.s_full = plan_items(&a, SYM_OFF, n, 1, 0, tiles_of(n), cus, 2, slots < 16 ? slots : 16, true);
     sp.col_cap = COL_CAP_MAX;
     if (const char* e = getenv("TVBF_SYM_COL_CAP")) sp.col_cap = atoi(e);  // tuning / test aid
     if (sp.col_cap < 1) sp.col_cap = 1;
