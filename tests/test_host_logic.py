@@ -471,3 +471,36 @@ def test_sharded_topk_symmetric_gloo(pkg, n, world):
 
     check_topk_against_scores(z @ z.T, 0, k, min_sim, ret["idx"], ret["score"], ret["count"], tol=1e-6,
                               what=f"gloo symmetric shards n={n} world={world}", check_tie_order=False)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 5, 6, 7, 8, 9, 16])
+@pytest.mark.parametrize("n", [10, 1000, 1001, 100_000, 99_999])
+def test_symmetric_partition_covers_every_pair_once(pkg, world, n):
+    """Pure arithmetic of the symmetric sharded route: own blocks, the half pieces and the second
+    sweep of the upper partners together hold every unordered pair of different shards' shows
+    exactly once (counted with interval sizes, no GPU and no process group)."""
+    from tvbingefriend_recommendation_service_amd import sharding
+
+    shards = [sharding.shard_bounds(n, world, r) for r in range(world)]
+    owner = np.repeat(np.arange(world), [s.rows for s in shards])  # shard of every show
+    assert len(owner) == n
+    covered = np.zeros((world, world), dtype=np.int64)  # [row shard, column shard] -> show pairs computed there
+    for s in shards:
+        for first, rows in sharding.half_pieces(s):
+            if rows:
+                cols = owner[first : first + rows]
+                assert (cols != s.rank).all(), "a rank's half pieces never hold its own columns"
+                for c in np.unique(cols):
+                    covered[s.rank, c] += s.rows * int((cols == c).sum())
+        pt = sharding.partner(world, s.rank)
+        if pt is not None and s.rank >= world // 2:
+            h0 = sharding.partner_split(s, s.rank)
+            assert 0 <= h0 <= s.rows and (h0 % 128 == 0 or h0 == s.rows)
+            covered[s.rank, pt] += (s.rows - h0) * shards[pt].rows
+    for a in range(world):
+        for b in range(a + 1, world):
+            assert covered[a, b] + covered[b, a] == shards[a].rows * shards[b].rows, (world, n, a, b)
+    # balance: no rank computes much more than the mean
+    work = covered.sum(axis=1)
+    if n >= 1000 and world > 1:
+        assert work.max() <= 1.1 * work.mean() + 2 * 128 * max(s.rows for s in shards)
