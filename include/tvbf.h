@@ -218,6 +218,8 @@ int tvbf_topk_finish(int64_t nq, int k, int slots, int32_t* out_idx, float* out_
  *                           overflow words: word 0 = some buffer overflowed, words 4 .. 4+n_total-1
  *                           = this show's buffer overflowed; cap: candidates kept per show (<= 1024)
  *   tvbf_topk_colside_begin clears the overflow words, the counters and the buffers
+ *   tvbf_topk_colside_reset the same for a state that went through begin and one job with the
+ *                           same n_total and cap: clears only the entries that job wrote
  *   tvbf_topk_accumulate_ex tvbf_topk_accumulate_f32 plus, with colside != NULL, the column side
  *                           (d % 64 == 0): a (score, global row) key above col_bound[column]
  *                           is appended to that column's buffer; with
@@ -254,6 +256,7 @@ int tvbf_topk_accumulate_sym_f32(const float* Zq, int64_t nq, int64_t q_row0, in
                                  const tvbf_colside* colside, void* stream);
 size_t tvbf_topk_colside_bytes(int64_t n_total, int cap);
 int tvbf_topk_colside_begin(void* state, size_t state_bytes, int64_t n_total, int cap, void* stream);
+int tvbf_topk_colside_reset(void* state, size_t state_bytes, int64_t n_total, int cap, void* stream);
 int tvbf_topk_accumulate_ex_f32(const float* Zq, int64_t nq, int64_t q_row0, int64_t d, int64_t ld,
                                 const float* ZcA, int64_t nA, int64_t colA, const float* ZcB, int64_t nB,
                                 int64_t colB, int k, float min_similarity, int exclude_self, void* workspace,

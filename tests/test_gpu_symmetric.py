@@ -184,7 +184,7 @@ def test_symmetric_benchmark_shape_sample(pkg, device):
     assert torch.equal(sym.score, plain.score)
 
 
-def _lockstep_ranks(device, z, n, world, k, ms, col_cap=1024):
+def _lockstep_ranks(device, z, n, world, k, ms, col_cap=1024, sides=None):
     """All ranks of a symmetric sharded job on one GPU, phase by phase, with the collectives
     replaced by indexing; returns the concatenated lists and the reduced overflow flag."""
     import torch
@@ -195,7 +195,8 @@ def _lockstep_ranks(device, z, n, world, k, ms, col_cap=1024):
     per = shards[0].per_rank
     z_all = torch.zeros((per * world, z.shape[1]), device=device)
     z_all[:n] = z[:n]
-    jobs = [sharding.SymmetricShardJob(z_all[r * per : (r + 1) * per], sh, k, ms, col_cap=col_cap)
+    jobs = [sharding.SymmetricShardJob(z_all[r * per : (r + 1) * per], sh, k, ms, col_cap=col_cap,
+                                       colside=None if sides is None else sides[r])
             for r, sh in enumerate(shards)]
     for j in jobs:
         j.phase_own()
@@ -383,3 +384,20 @@ def test_topk_calls_can_be_captured_in_a_graph(pkg, device):
             graph.replay()
             torch.cuda.synchronize()
             _assert_same(out, ref, f"{name} replay {rep}")
+
+
+def test_column_side_state_is_reusable(pkg, device):
+    """A rank keeps one column-side state for all its jobs: after the first job only the entries
+    that job wrote are cleared.  A job on tie-heavy data (full buffers, refreshed bounds) followed
+    by jobs on other catalogues of the same size must leave no trace."""
+    from tvbingefriend_recommendation_service_amd import engine, sharding
+
+    n, k, world = 9000, 20, 3
+    per = sharding.shard_bounds(n, world, 0).per_rank
+    sides = [engine.ColumnSide(per * world, device) for _ in range(world)]
+    cases = [(_with_clique(device, n, 2500, 128, seed=51), -1.0), (_z_hybrid(device, n, seed=52)[0], 0.1),
+             (_with_clique(device, n, 700, 128, seed=53), -1.0)]
+    for z, ms in cases:
+        plain = engine.cosine_topk(z, k, ms)
+        got, _ = _lockstep_ranks(device, z, n, world, k, ms, sides=sides)
+        _assert_same(got, plain, "reused column-side state")

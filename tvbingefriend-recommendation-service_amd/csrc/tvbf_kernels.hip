@@ -1554,6 +1554,24 @@ __global__ __launch_bounds__(256) void zero16_kernel(uint4* __restrict__ p, int6
         p[i] = uint4{0u, 0u, 0u, 0u};
 }
 
+// Column-side state that has been through tvbf_topk_colside_begin and one job: only the entries the
+// job wrote are cleared (one wavefront per show), then the show's counter and overflow word.
+__global__ __launch_bounds__(256) void colside_reset_kernel(unsigned* __restrict__ flags, unsigned* __restrict__ cnt,
+                                                            u64* __restrict__ buf, int64_t n_total, int cap) {
+    const int lane = threadIdx.x & 63;
+    const int64_t show = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blockIdx.x == 0 && threadIdx.x < OVF_SHOWS) flags[threadIdx.x] = 0u;
+    if (show >= n_total) return;
+    unsigned c = cnt[show];
+    if (c > (unsigned)cap) c = (unsigned)cap;
+    u64* b = buf + show * cap;
+    for (unsigned i = lane; i < c; i += 64) b[i] = 0ull;
+    if (lane == 0) {
+        cnt[show] = 0u;
+        flags[OVF_SHOWS + show] = 0u;
+    }
+}
+
 __global__ __launch_bounds__(256) void fill_u32_kernel(unsigned* __restrict__ p, int64_t count, unsigned v) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) p[i] = v;
@@ -2400,6 +2418,18 @@ int tvbf_topk_colside_begin(void* state, size_t state_bytes, int64_t n_total, in
     }
     hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<unsigned*>(state), words, 0u);
+    HIP_TRY(hipGetLastError());
+    return TVBF_OK;
+}
+
+int tvbf_topk_colside_reset(void* state, size_t state_bytes, int64_t n_total, int cap, void* stream) {
+    if (!state || ((uintptr_t)state & 15)) return fail(TVBF_E_BAD_ARG, "null or misaligned state");
+    if (!tvbf_topk_colside_bytes(n_total, cap) || state_bytes < tvbf_topk_colside_bytes(n_total, cap))
+        return fail(TVBF_E_BAD_SHAPE, "state smaller than tvbf_topk_colside_bytes()");
+    char* st = reinterpret_cast<char*>(state);
+    hipLaunchKernelGGL(colside_reset_kernel, dim3((unsigned)((n_total + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<unsigned*>(st), reinterpret_cast<unsigned*>(st + cs_cnt_off(n_total)),
+                       reinterpret_cast<u64*>(st + cs_buf_off(n_total)), n_total, cap);
     HIP_TRY(hipGetLastError());
     return TVBF_OK;
 }

@@ -605,12 +605,17 @@ class ColumnSide:
             raise ValueError("n_total >= 1 and 1 <= cap <= 1024")
         self.state = torch.empty((self.bytes + 15) // 16 * 2, dtype=torch.int64, device=self.dev)
         self._struct = None
+        self._clean = False
         self.begin()
 
     def begin(self) -> None:
+        """Ready for a new job: the first time everything is cleared, afterwards only what the
+        previous job wrote (its counters say how much)."""
+        fn = self.lib.tvbf_topk_colside_reset if self._clean else self.lib.tvbf_topk_colside_begin
         with torch.cuda.device(self.dev):
-            rc = self.lib.tvbf_topk_colside_begin(self.state.data_ptr(), self.bytes, self.n_total, self.cap, _stream_ptr())
-        native.check(rc, "tvbf_topk_colside_begin")
+            rc = fn(self.state.data_ptr(), self.bytes, self.n_total, self.cap, _stream_ptr())
+        native.check(rc, "tvbf_topk_colside_begin / reset")
+        self._clean = True
 
     @property
     def flags(self) -> torch.Tensor:

@@ -36,6 +36,7 @@ SYMBOLS = (
     "tvbf_topk_finish",
     "tvbf_topk_colside_bytes",
     "tvbf_topk_colside_begin",
+    "tvbf_topk_colside_reset",
     "tvbf_topk_accumulate_ex_f32",
     "tvbf_topk_accumulate_sym_f32",
     "tvbf_topk_colside_reduce",
@@ -151,6 +152,8 @@ def load() -> ctypes.CDLL:
     lib.tvbf_topk_colside_bytes.argtypes = [i64, c.c_int]
     lib.tvbf_topk_colside_begin.restype = c.c_int
     lib.tvbf_topk_colside_begin.argtypes = [vp, sz, i64, c.c_int, vp]
+    lib.tvbf_topk_colside_reset.restype = c.c_int
+    lib.tvbf_topk_colside_reset.argtypes = [vp, sz, i64, c.c_int, vp]
     lib.tvbf_topk_accumulate_ex_f32.restype = c.c_int
     lib.tvbf_topk_accumulate_ex_f32.argtypes = [vp, i64, i64, i64, i64, vp, i64, i64, vp, i64, i64, c.c_int, f32,
                                                 c.c_int, vp, sz, c.c_int, c.c_int, c.POINTER(c.c_int),
