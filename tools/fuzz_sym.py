@@ -1,5 +1,5 @@
 """Random shapes and parameters: symmetric sweep (single catalogue and sharded job in lockstep)
-against the plain sweep, bitwise.  usage: fuzz_sym.py [CASES] [SEED]"""
+against the plain sweep, bitwise.  usage: fuzz_sym.py [CASES] [SEED] [MAX_N]"""
 import os, sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -10,6 +10,7 @@ from tvbingefriend_recommendation_service_amd import engine, sharding
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+max_n = int(sys.argv[3]) if len(sys.argv) > 3 else 7000
 dev = torch.device("cuda:0")
 
 
@@ -38,7 +39,7 @@ def lockstep(z, n, world, k, ms):
 
 bad = 0
 for c in range(cases):
-    n = int(rng.integers(300, 7000))
+    n = int(rng.integers(300, max_n))
     d = 64 * int(rng.integers(1, 6))
     k = int(rng.choice([1, 3, 7, 20, 24, 30, 31, 50, 100]))
     ms = float(rng.choice([-1.0, 0.0, 0.05, 0.3]))
