@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Phase breakdown of the LDS-DMA kernels' k-block pair loop (needs a timing-only build made with
+-DTVBF_DIAG_TIMELINE; such a build is never shipped):
+
+    TVBF_LIB=build/libtvbf_timeline.so python tools/timeline_dma.py [n] [d] [k] [plain|symmetric]
+
+Every wavefront sums the cycle-counter time between the marks of a pair of k-blocks:
+  issueA  LDS-DMA transfers and query loads of the next k-block issued
+  mfmaA   fragment reads + 64 MFMAs issued (first k-block of the pair)
+  barA    wait for the own transfers + workgroup barrier
+  issueB / mfmaB / barB   the same for the second k-block
+  epi     epilogue (last pair of a tile only)
+  top     per-tile work before the pair loop
+With the symmetric sweep the half sweep is the launch that is recorded last in the buffer."""
+import os
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import numpy as np
+import torch
+
+import tvbf_amd  # noqa: F401
+from tvbingefriend_recommendation_service_amd import engine
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
+d = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+k = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+sweep = sys.argv[4] if len(sys.argv) > 4 else "plain"
+dev = torch.device("cuda:0")
+x = torch.zeros((n, d), device=dev)
+x[:, :32] = (torch.rand((n, 32), device=dev) < 0.08).float()
+t_ = torch.randn((n, d - 64), device=dev).abs_()
+t_ *= torch.rand((n, d - 64), device=dev) < 0.03
+x[:, 32:d - 32] = t_
+del t_
+x[torch.arange(n, device=dev), d - 32 + torch.randint(0, 32, (n,), device=dev)] = 1.0
+z = engine.normalize_blocks(x, [0, 32, d - 32, d], [0.4 ** 0.5, 0.5 ** 0.5, 0.1 ** 0.5])
+del x
+run = (lambda: engine.cosine_topk(z, k, 0.1)) if sweep == "plain" else (lambda: engine.cosine_topk_symmetric(z, k, 0.1))
+run()
+torch.cuda.synchronize()
+buf = torch.zeros((1 << 12, 4, 16), dtype=torch.int64, device=dev)
+os.environ["TVBF_DIAG_BUF"] = hex(buf.data_ptr())
+t0 = time.perf_counter()
+run()
+torch.cuda.synchronize()
+wall = time.perf_counter() - t0
+raw = buf.cpu().numpy().astype(np.float64)
+raw = raw[raw[:, 0, 8] > 0]
+names = ["issueA", "mfmaA", "barA", "issueB", "mfmaB", "epi", "barB", "top"]
+tot = raw[..., :8].sum(axis=(0, 1))
+pairs, tiles = raw[..., 8].sum(), raw[..., 9].sum()
+print(f"{len(raw)} workgroups, {int(pairs)} wave-pairs, {int(tiles)} wave-tiles, call wall {wall * 1e3:.1f} ms")
+print(f"cycles per pair of k-blocks (128 MFMAs = 8192 pipe cycles of this wave): {tot.sum() / pairs:.0f}")
+for nme, v in zip(names, tot):
+    print(f"{nme:7s} {v / pairs:8.1f} per pair  {100 * v / tot.sum():5.1f} %")
+print(f"epilogue per tile and wave: {tot[5] / tiles:.0f} cycles; per-tile top: {tot[7] / tiles:.0f}")
+print(f"in the loop: {100 * tot.sum() / raw[..., 10].sum():.1f} % of the waves' lifetime")

@@ -1039,6 +1039,21 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     if (COLSIDE && tid == 0) *lcnt = 0u;
+#ifdef TVBF_DIAG_TIMELINE  // timing-only build: every wave sums the cycle-counter time of the phases of a k-block pair
+    unsigned long long* dl_buf = reinterpret_cast<unsigned long long*>(a.gram);
+    unsigned long long dl[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dl_prev = __builtin_readcyclecounter(), dl_pairs = 0, dl_tiles = 0;
+    const unsigned long long dl_start = dl_prev;
+#define DL_MARK(i)                                               \
+    do {                                                         \
+        __builtin_amdgcn_sched_barrier(0);                       \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        dl[i] += now_ - dl_prev;                                 \
+        dl_prev = now_;                                          \
+        __builtin_amdgcn_sched_barrier(0);                       \
+    } while (0)
+#else
+#define DL_MARK(i) do { } while (0)
+#endif
 
     // ---- this workgroup's stretch of the line of column tiles ----
     int64_t x_pos = (a.total_tiles * (int64_t)blockIdx.x) / a.items;
@@ -1132,8 +1147,10 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
         const char* cb = tile_ptr + (size_t)kb * (BK * 4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            // a copy made opaque: the widening to 64 bits stays next to the use (scalar base + 32-bit
+            // offset).  Laundering coff[i] in place saves the v_mov but measured 1.2 % slower.
             unsigned off = coff[i];
-            asm volatile("" : "+v"(off));  // the widening to 64 bits stays next to the use: scalar base + 32-bit offset
+            asm volatile("" : "+v"(off));
             __builtin_amdgcn_global_load_lds((global_cvoid_t)(cb + off),
                                              (lds_void_t*)(buffer + i * 1024 + wave * 256), 16, 0, 0);
         }
@@ -1203,16 +1220,20 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
                 if (tid == 0) *lcnt = 0u;
             }
         }
+        DL_MARK(7);
 #pragma nounroll
         for (int kb = 0; kb < nkb; kb += 2) {
             dma_tile(kb + 1, tileC1);
             load_q(kb + 1, qreg[1]);
             __builtin_amdgcn_sched_barrier(0);  // the transfers leave before the MFMAs, not after them
+            DL_MARK(0);
             mfma_block(tileC0, qreg[0]);
+            DL_MARK(1);
             // all 64 MFMAs are issued before the wait for this k-block's transfers (the compiler
             // would otherwise sink half of them below the barrier and wait for memory too early)
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
+            DL_MARK(2);
             const bool last = kb + 2 >= nkb;
             if (!last || ct + 1 < tile_end) {  // one issue site for "next k-block" and "first k-block of the next tile"
                 if (last) set_tile(ct + 1);
@@ -1221,7 +1242,9 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
                 load_q(next_kb, qreg[0]);
             }
             __builtin_amdgcn_sched_barrier(0);
+            DL_MARK(3);
             mfma_block(tileC1, qreg[1]);
+            DL_MARK(4);
             if (last) {
                 if (my_gb) {
                     gbf = fmaxf(gbf, ordered_to_f32(gb_bits));
@@ -1394,8 +1417,14 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
             }
+            DL_MARK(5);
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
+            DL_MARK(6);
+#ifdef TVBF_DIAG_TIMELINE
+            ++dl_pairs;
+            dl_tiles += last ? 1 : 0;
+#endif
         }
     }
 
@@ -1426,6 +1455,15 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
         if (queued_cols > (unsigned)a.col_lds) queued_cols = (unsigned)a.col_lds;
         col_drain(a, lrowg, lkey, queued_cols, tid, lane, reinterpret_cast<u64*>(scratch));
     }
+#ifdef TVBF_DIAG_TIMELINE
+    if (dl_buf && lane == 0) {
+        unsigned long long* o = dl_buf + ((size_t)blockIdx.x * 4 + wave) * 16;
+        for (int i = 0; i < 8; ++i) o[i] = dl[i];
+        o[8] = dl_pairs;
+        o[9] = dl_tiles;
+        o[10] = __builtin_readcyclecounter() - dl_start;
+    }
+#endif
 }
 
 __global__ __launch_bounds__(256) void bound_init_kernel(u64* __restrict__ bound, int64_t nq, u64 v) {
@@ -2361,6 +2399,9 @@ int tvbf_topk_accumulate_sym_f32(const float* Zq, int64_t nq, int64_t q_row0, in
     a.col_cap = colside->cap;
     a.col_lds = col_lds;
     a.col_drain = colside_drain_at(col_lds);
+#ifdef TVBF_DIAG_TIMELINE
+    if (const char* e = getenv("TVBF_DIAG_BUF")) a.gram = reinterpret_cast<float*>(strtoull(e, nullptr, 0));
+#endif
     u64* lists = reinterpret_cast<u64*>(ws + ws_bound_bytes(nq)) + (size_t)slot0 * nq * k;
     const bool list_global = topk_list_global(k);
     const void* k_diag = list_global ? reinterpret_cast<const void*>(cosine_topk_dma_kernel<true, SYM_DIAG>)
