@@ -1166,7 +1166,7 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
     };
     // One k-block: the MFMAs of the tile in `cur` with the query fragments `q`; its transfers for the
     // next k-block were issued by the caller.  Fragment reads run one 8-deep step ahead.
-    auto mfma_block = [&](const float* cur, const f32x4(&q)[4], auto&& issue_next) __attribute__((always_inline)) {
+    auto mfma_block = [&](const float* cur, const f32x4(&q)[4]) __attribute__((always_inline)) {
         const char* cbytes = reinterpret_cast<const char*>(cur);
         f32x4 cf[NJ];
 #pragma unroll
@@ -1188,15 +1188,6 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(cf[j][i], q[t][i], acc[j], 0, 0, 0);
             if (t < 3) __builtin_amdgcn_sched_group_barrier(0x100, NJ, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 4 * NJ, 0);
-            if (t == 0) {
-                // the transfers and query loads of the next k-block go out in the shadow of the first
-                // sixteen MFMAs: while this wave streams MFMAs it owns the pipe, and other instructions
-                // issued in between cost next to nothing; as a phase of their own they wait behind the
-                // other wave's MFMAs
-                __builtin_amdgcn_sched_barrier(0);
-                issue_next();
-                __builtin_amdgcn_sched_barrier(0);
-            }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) cf[j] = cn[j];
         }
@@ -1232,11 +1223,11 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
         DL_MARK(7);
 #pragma nounroll
         for (int kb = 0; kb < nkb; kb += 2) {
+            dma_tile(kb + 1, tileC1);
+            load_q(kb + 1, qreg[1]);
+            __builtin_amdgcn_sched_barrier(0);  // the transfers leave before the MFMAs, not after them
             DL_MARK(0);
-            mfma_block(tileC0, qreg[0], [&]() {
-                dma_tile(kb + 1, tileC1);
-                load_q(kb + 1, qreg[1]);
-            });
+            mfma_block(tileC0, qreg[0]);
             DL_MARK(1);
             // all 64 MFMAs are issued before the wait for this k-block's transfers (the compiler
             // would otherwise sink half of them below the barrier and wait for memory too early)
@@ -1244,15 +1235,15 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
             __syncthreads();
             DL_MARK(2);
             const bool last = kb + 2 >= nkb;
+            if (!last || ct + 1 < tile_end) {  // one issue site for "next k-block" and "first k-block of the next tile"
+                if (last) set_tile(ct + 1);
+                const int next_kb = last ? 0 : kb + 2;
+                dma_tile(next_kb, tileC0);
+                load_q(next_kb, qreg[0]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
             DL_MARK(3);
-            mfma_block(tileC1, qreg[1], [&]() {
-                if (!last || ct + 1 < tile_end) {  // one issue site for "next k-block" and "first k-block of the next tile"
-                    if (last) set_tile(ct + 1);
-                    const int next_kb = last ? 0 : kb + 2;
-                    dma_tile(next_kb, tileC0);
-                    load_q(next_kb, qreg[0]);
-                }
-            });
+            mfma_block(tileC1, qreg[1]);
             DL_MARK(4);
             if (last) {
                 if (my_gb) {
