@@ -1043,6 +1043,7 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
     unsigned long long* dl_buf = reinterpret_cast<unsigned long long*>(a.gram);
     unsigned long long dl[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dl_prev = __builtin_readcyclecounter(), dl_pairs = 0, dl_tiles = 0;
     const unsigned long long dl_start = dl_prev;
+    const unsigned long long dl_wall0 = wall_clock64();  // 100 MHz, one counter for the whole device
 #define DL_MARK(i)                                               \
     do {                                                         \
         __builtin_amdgcn_sched_barrier(0);                       \
@@ -1462,6 +1463,10 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
         o[8] = dl_pairs;
         o[9] = dl_tiles;
         o[10] = __builtin_readcyclecounter() - dl_start;
+        o[11] = dl_wall0;
+        o[12] = wall_clock64();
+        o[13] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |        // HW_ID: cu, sh, se
+                ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);  // XCC_ID
     }
 #endif
 }
