@@ -1485,7 +1485,10 @@ constexpr int FIN_ROWS = 2;  // rows (wavefronts) per workgroup
 
 // `gate` (may be null) points at the per-row overflow flags of these nq rows: a flagged row merges
 // the lists [alt_first, alt_first + alt_splits) -- the plain re-run of its row block -- instead.
-__global__ __launch_bounds__(64 * FIN_ROWS) void topk_finalize_kernel(const u64* __restrict__ partial, int64_t nq,
+// `bound` (may be null): the rows' bound keys.  Each is the K-th best of some set of real candidates
+// of its row, hence not above the row's final K-th key: keys below it are left out before ranking.
+__global__ __launch_bounds__(64 * FIN_ROWS) void topk_finalize_kernel(const u64* __restrict__ bound,
+                                                            const u64* __restrict__ partial, int64_t nq,
                                                             int k, int splits, int32_t* __restrict__ out_idx,
                                                             float* __restrict__ out_score,
                                                             int32_t* __restrict__ out_count,
@@ -1504,6 +1507,7 @@ __global__ __launch_bounds__(64 * FIN_ROWS) void topk_finalize_kernel(const u64*
     }
     u64* b = buf[wave];
     const int m = (splits + n_extra) * k;
+    const u64 floor_key = bound ? bound[row] : 0ull;
     // gather the non-empty keys of all partial lists, packed (most slots of late splits are empty
     // because the shared bound rejected their columns); `extra` lists (received from other ranks)
     // have the same format, list e at extra + e * extra_stride
@@ -1516,7 +1520,7 @@ __global__ __launch_bounds__(64 * FIN_ROWS) void topk_finalize_kernel(const u64*
             key = s < splits ? partial[((int64_t)s * nq + row) * k + (i - s * k)]
                              : extra[(int64_t)(s - splits) * extra_stride + row * k + (i - s * k)];
         }
-        const bool real = (uint32_t)key != 0u;
+        const bool real = (uint32_t)key != 0u && key >= floor_key;
         const u64 mask = __ballot(real);
         if (real) b[packed + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = key;
         packed += __builtin_popcountll(mask);
@@ -2520,15 +2524,17 @@ int tvbf_topk_finish_ex(int64_t nq, int k, int slots, const uint64_t* extra, int
     if (nq == 0) return TVBF_OK;
     const char* ws = reinterpret_cast<const char*>(workspace);
     hipLaunchKernelGGL(topk_finalize_kernel, dim3((unsigned)((nq + FIN_ROWS - 1) / FIN_ROWS)), dim3(64 * FIN_ROWS), 0,
-                       (hipStream_t)stream, reinterpret_cast<const u64*>(ws + ws_bound_bytes(nq)), nq, k, slots, out_idx,
-                       out_score, out_count, gate, alt_first, alt_slots, reinterpret_cast<const u64*>(extra), n_extra,
+                       (hipStream_t)stream, reinterpret_cast<const u64*>(ws),
+                       reinterpret_cast<const u64*>(ws + ws_bound_bytes(nq)), nq, k, slots, out_idx, out_score,
+                       out_count, gate, alt_first, alt_slots, reinterpret_cast<const u64*>(extra), n_extra,
                        extra_stride);
     HIP_TRY(hipGetLastError());
     return TVBF_OK;
 }
 
-int tvbf_topk_finish(int64_t nq, int k, int slots, int32_t* out_idx, float* out_score, int32_t* out_count,
-                     const void* workspace, size_t workspace_bytes, void* stream) {
+// with_bounds: the workspace went through tvbf_topk_begin, so its bound keys can thin the merge
+static int finish_lists(int64_t nq, int k, int slots, int32_t* out_idx, float* out_score, int32_t* out_count,
+                        const void* workspace, size_t workspace_bytes, void* stream, bool with_bounds) {
     int rc = check_topk_common(nq, k, workspace);
     if (rc) return rc;
     if (!out_idx || !out_score || !out_count) return fail(TVBF_E_BAD_ARG, "null pointer argument");
@@ -2538,11 +2544,16 @@ int tvbf_topk_finish(int64_t nq, int k, int slots, int32_t* out_idx, float* out_
     if (nq == 0) return TVBF_OK;
     const char* ws = reinterpret_cast<const char*>(workspace);
     hipLaunchKernelGGL(topk_finalize_kernel, dim3((unsigned)((nq + FIN_ROWS - 1) / FIN_ROWS)), dim3(64 * FIN_ROWS), 0,
-                       (hipStream_t)stream,
+                       (hipStream_t)stream, with_bounds ? reinterpret_cast<const u64*>(ws) : (const u64*)nullptr,
                        reinterpret_cast<const u64*>(ws + ws_bound_bytes(nq)), nq, k, slots, out_idx, out_score,
                        out_count, (const unsigned*)nullptr, 0, 0, (const u64*)nullptr, 0, (int64_t)0);
     HIP_TRY(hipGetLastError());
     return TVBF_OK;
+}
+
+int tvbf_topk_finish(int64_t nq, int k, int slots, int32_t* out_idx, float* out_score, int32_t* out_count,
+                     const void* workspace, size_t workspace_bytes, void* stream) {
+    return finish_lists(nq, k, slots, out_idx, out_score, out_count, workspace, workspace_bytes, stream, true);
 }
 
 int tvbf_cosine_topk_f32(const float* Zq, int64_t nq, int64_t q_row0, const float* Zall, int64_t n, int64_t d,
@@ -2750,7 +2761,8 @@ int tvbf_query_topk_f32(const float* Zq, int64_t nq, int64_t ldq, const int64_t*
                            scores + q0 * n, n, (int)nq, self, k, min_similarity, lists, partial + q0 * k);
         HIP_TRY(hipGetLastError());
     }
-    return tvbf_topk_finish(nq, k, lists, out_idx, out_score, out_count, workspace, workspace_bytes, stream);
+    // the selection waves keep no bound keys: the head of the workspace is not initialised here
+    return finish_lists(nq, k, lists, out_idx, out_score, out_count, workspace, workspace_bytes, stream, false);
 }
 
 int tvbf_gram_f32(const float* Zq, int64_t nq, const float* Zall, int64_t n, int64_t d, int64_t ld, float* out,

@@ -241,15 +241,15 @@ class SymmetricShardJob:
         send = torch.zeros((sh.world, sh.per_rank, self.k), dtype=torch.int64, device=self.dev)  # zero = empty slot
         if sh.rows == 0:
             return send
-        fed = list(half_peers(sh.world, sh.rank))
-        pt = partner(sh.world, sh.rank)
-        if pt is not None:
-            fed.append(pt)
-        for p in fed:
-            r0 = min(p * sh.per_rank, sh.n)
-            rows = min((p + 1) * sh.per_rank, sh.n) - r0
-            if rows > 0:
-                self.side.reduce(bounds_all, r0, rows, self.k, self.min_similarity, send[p])
+        # the fed shards follow this one cyclically (the partner last), and a show's global index
+        # is also its row in the (world * per_rank)-row view of `send`: one reduction per run of shards
+        fed = len(half_peers(sh.world, sh.rank)) + (1 if partner(sh.world, sh.rank) is not None else 0)
+        flat = send.view(sh.world * sh.per_rank, self.k)
+        first = sh.rank + 1
+        for p0, p1 in ((first, min(first + fed, sh.world)), (0, first + fed - sh.world)):
+            a, b = min(p0 * sh.per_rank, sh.n), min(p1 * sh.per_rank, sh.n)
+            if p1 > p0 and b > a:
+                self.side.reduce(bounds_all, a, b - a, self.k, self.min_similarity, flat[a:b])
         return send
 
     @property
