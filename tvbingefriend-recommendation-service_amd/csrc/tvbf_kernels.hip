@@ -2034,7 +2034,14 @@ static int plan_items(TopkArgs* a, int sym, int64_t nq, int shards, int64_t n_al
     }
     // a list is only as good a filter as the columns it has seen: no stretch shorter than four tiles
     // (small jobs then run on fewer workgroups)
-    if (items > total / 4) items = total / 4 > 0 ? total / 4 : 1;
+    // (two in the own-columns sweep, whose short column ranges would otherwise leave most of a small
+    // job's workgroups without work; it has no column side to flood)
+    int64_t shortest = sym == SYM_DIAG ? 2 : 4;
+    if (const char* e = getenv("TVBF_MIN_STRETCH")) {  // tuning aid; any value gives the same result
+        const int64_t vset = atoll(e);
+        if (vset >= 1) shortest = vset;
+    }
+    if (items > total / shortest) items = total / shortest > 0 ? total / shortest : 1;
     if (max_slots < 1) max_slots = 1;
     for (;;) {
         const int64_t len = total / items;  // shortest stretch
