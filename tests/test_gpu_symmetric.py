@@ -72,6 +72,27 @@ def test_symmetric_equals_plain_hybrid(pkg, device, monkeypatch, n, shards):
         _assert_same(sym, plain, f"n={n} shards={shards} k={k}")
 
 
+@pytest.mark.parametrize("knob,value", [("TVBF_ITEMS", "37"), ("TVBF_ITEMS", "1000"), ("TVBF_MIN_STRETCH", "1"),
+                                        ("TVBF_MIN_STRETCH", "9"), ("TVBF_COL_DRAIN", "16")])
+def test_work_partition_never_changes_the_lists(pkg, device, monkeypatch, knob, value):
+    """How the tiles are cut into stretches (and when the column queue is drained) moves work
+    between workgroups, nothing else: both sweeps give the lists of the default partition."""
+    import torch
+
+    from tvbingefriend_recommendation_service_amd import engine
+
+    monkeypatch.setenv("TVBF_SYM_SHARDS", "6")
+    z, _, _ = _z_hybrid(device, 2500, seed=77)
+    want = engine.cosine_topk(z, 20, 0.1)
+    torch.cuda.synchronize()
+    monkeypatch.setenv(knob, value)
+    plain = engine.cosine_topk(z, 20, 0.1)
+    sym = _sym(z, 20, 0.1)
+    torch.cuda.synchronize()
+    _assert_same(plain, want, f"plain sweep with {knob}={value}")
+    _assert_same(sym, want, f"symmetric sweep with {knob}={value}")
+
+
 @pytest.mark.parametrize("n,d,k", [(1300, 64, 24), (3000, 128, 20), (1025, 192, 1)])
 def test_symmetric_dense_against_oracle(pkg, device, monkeypatch, n, d, k):
     """No min_similarity cut, negative scores in the lists: against the float64 oracle and the plain sweep."""
