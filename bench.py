@@ -324,12 +324,16 @@ def main():
             traffic = json.loads(tf.read_text()).get(key)
         except Exception:
             traffic = None
-    # share of the ordered pairs the sweeps really compute (1 for the plain sweep): with V shards the
-    # own-columns sweeps take 1/V (both orders), every pair of different shards is computed once
+    # share of the ordered pairs the sweeps really compute (1 for the plain sweep): every pair of
+    # different shards is computed once; a shard's own block, 1/V of all pairs, is computed in both
+    # orders, or -- a shard of 16 or more row blocks -- as a ring of U = 4 sub-shards in the same way
     share = 1.0
     if symmetric and world == 1:
-        v = max(2, min(32, ((nq + 127) // 128) // 8))
-        share = 1.0 / v + (v - 1) / (2.0 * v)
+        row_blocks = (nq + 127) // 128
+        v = max(2, min(32, row_blocks // 8))
+        u = 4 if row_blocks // v >= 16 else 1
+        own = 1.0 if u == 1 else 1.0 / u + (u - 1) / (2.0 * u)
+        share = own / v + (v - 1) / (2.0 * v)
     elif symmetric:
         share = None  # per rank: own block symmetric + (world - 1) / 2 foreign blocks; see the design notes
     line = {

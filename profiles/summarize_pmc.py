@@ -4,8 +4,8 @@ time of profiles/collect_stats.sh (gpurun_out/stats_<tag>/) into the JSON summar
 profiles/:   python profiles/summarize_pmc.py <tag> plain|symmetric
 
 plain:     the general sweep, cosine_topk_dma_kernel<false, 0, false> (bench.py --sweep plain)
-symmetric: the own-columns sweep <false, 1, false> plus the half sweep <false, 2, true> of one call
-           (bench.py default on one GPU); their counters and times are added up."""
+symmetric: the own-columns sweep <false, 1, false> plus the half sweeps <false, 2, true> of one call
+           (bench.py default on one GPU); their counters and times are added up per call."""
 import collections
 import csv
 import glob
@@ -32,14 +32,21 @@ for name in ("sq1", "sq2", "tcc1", "tcc2"):
                 calls[(kern, r["Counter_Name"])] += 1
     tot = collections.defaultdict(float)
     for (kern, c), v in agg.items():
-        tot[c] += v / calls[(kern, c)]  # per launch, summed over the kernels of one call
+        # per call of the sweep: the first kernel is launched once per call, the half sweep of the
+        # symmetric route once or twice (inside the shards, then over them)
+        tot[c] += v / calls[(KERNELS[0], c)]
     res[name] = dict(tot)
-ms, per_kernel = 0.0, {}
-for r in csv.DictReader(open(stats / "kernel_stats.csv")):
+ms, per_kernel, sweep_calls = 0.0, {}, None
+rows = list(csv.DictReader(open(stats / "kernel_stats.csv")))
+for r in rows:
+    if KERNELS[0] in r["Name"]:
+        sweep_calls = int(r["Calls"])
+for r in rows:
     for kern in KERNELS:
         if kern in r["Name"]:
-            per_kernel[kern] = round(float(r["AverageNs"]) / 1e6, 3)
-            ms += float(r["AverageNs"]) / 1e6
+            per_call = float(r["TotalDurationNs"]) / sweep_calls / 1e6
+            per_kernel[kern] = {"ms_per_call": round(per_call, 3), "launches_per_call": int(r["Calls"]) // sweep_calls}
+            ms += per_call
 sq1 = res["sq1"]
 cyc = sq1["GRBM_GUI_ACTIVE"] / 8
 fetch = res["tcc1"]["FETCH_SIZE"] * 1024 * 2

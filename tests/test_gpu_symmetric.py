@@ -72,6 +72,28 @@ def test_symmetric_equals_plain_hybrid(pkg, device, monkeypatch, n, shards):
         _assert_same(sym, plain, f"n={n} shards={shards} k={k}")
 
 
+@pytest.mark.parametrize("n,shards,ring", [(4000, 4, 2), (4000, 4, 3), (4000, 4, 4), (2600, 2, 4), (2600, 2, 7),
+                                           (5000, 3, 13), (3000, 5, 2)])
+def test_symmetric_two_levels_equals_plain(pkg, device, monkeypatch, n, shards, ring):
+    """Every shard swept symmetrically itself (a ring of sub-shards: own columns, half sweep inside
+    the ring, bounds merged from row lists and column buffers) before the half sweep over the
+    shards: identical lists for even and odd rings, ragged sub-shards, rings of one row block."""
+    import torch
+
+    from tvbingefriend_recommendation_service_amd import engine
+
+    monkeypatch.setenv("TVBF_SYM_SHARDS", str(shards))
+    monkeypatch.setenv("TVBF_SYM_RING", str(ring))
+    z, _, _ = _z_hybrid(device, n, seed=900 + n + ring)
+    # (31, 0.05): lists in global memory; hundreds of shows tie at two shared metadata values, so a
+    # few column buffers may run full on these small matrices -- the lists must agree either way
+    for k, ms, overflow in ((20, 0.1, False), (31, 0.05, None)):
+        plain = engine.cosine_topk(z, k, ms)
+        sym = _sym(z, k, ms, expect_overflow=overflow)
+        torch.cuda.synchronize()
+        _assert_same(sym, plain, f"n={n} shards={shards} ring={ring} k={k}")
+
+
 @pytest.mark.parametrize("knob,value", [("TVBF_ITEMS", "37"), ("TVBF_ITEMS", "1000"), ("TVBF_MIN_STRETCH", "1"),
                                         ("TVBF_MIN_STRETCH", "9"), ("TVBF_COL_DRAIN", "16")])
 def test_work_partition_never_changes_the_lists(pkg, device, monkeypatch, knob, value):

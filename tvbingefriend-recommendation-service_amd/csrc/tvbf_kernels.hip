@@ -7,6 +7,7 @@
 //                             cut into equal stretches; symmetric variants feed the lists of the
 //                             column shows too, so that every pair of shows is computed once
 //   col_reduce_kernel         column-side buffers -> one more partial list per show
+//   bound_merge_kernel        row lists + column buffer of a show -> its bound key (between symmetric sweeps)
 //   topk_finalize_kernel      merge of the partial lists of a row
 //   component_scores_kernel   per-block cosines of the kept pairs
 //   query_*_kernel            a few query vectors against the whole catalogue (HBM-bound)
@@ -160,7 +161,8 @@ struct ColRange {
     int tiles;         // ceil(n / BN)
 };
 
-constexpr int MAX_SHARDS = 64;
+constexpr int MAX_SHARDS = 128;     // entries of a launch's shard table
+constexpr int MAX_TOP_SHARDS = 64;  // shards of the symmetric sweep's top level
 constexpr int OVF_SHOWS = 4;  // word offset of the per-show overflow flags behind the summary word
 
 struct TopkArgs {
@@ -181,8 +183,9 @@ struct TopkArgs {
     const unsigned* st_prefix;  // [2] key prefixes selected by the earlier levels
     int st_level, st_chunk;     // radix level 0..2; column tiles per workgroup
     // symmetric sweep (query rows and columns are the same matrix, given whole as rng[0]): the row
-    // blocks form `shards` groups of (nearly) equal size; the kernel derives each group's column ranges
-    int shards;
+    // blocks form `shards` groups of (nearly) equal size, these form rings of `ring` consecutive
+    // shards; the kernel derives each group's column ranges (shard_spans)
+    int shards, ring;
     // work of the LDS-DMA kernels: the column tiles of all row blocks form one line (row block
     // after row block; a row block of shard v has sh_tiles[v] of them), cut into `items` equal
     // stretches, one per workgroup.  A workgroup walks through the row blocks its stretch touches;
@@ -899,11 +902,13 @@ constexpr int DMA_SLOTS = 8;  // scores a lane can queue per collect pass
 enum { SYM_OFF = 0, SYM_DIAG = 1, SYM_HALF = 2 };
 
 // Rows [a0, a1) and [b0, b1) of the matrix that shard v sweeps as columns.  Shard s = row blocks
-// [s * RB / V, (s + 1) * RB / V): sizes differ by one block at most.
+// [s * RB / V, (s + 1) * RB / V): sizes differ by one block at most.  The V shards form V / U
+// rings of U consecutive shards; "the shards that follow" are taken cyclically inside the ring
+// (U == V: one ring, the whole matrix).
 struct ShardSpans {
     int64_t a0, a1, b0, b1;
 };
-__host__ __device__ static inline ShardSpans shard_spans(int sym, int v, int V, int RB, int64_t n_all) {
+__host__ __device__ static inline ShardSpans shard_spans(int sym, int v, int V, int U, int RB, int64_t n_all) {
     auto row_of = [=](int shard) {
         const int64_t r = (int64_t)(((int64_t)shard * RB) / V) * BM;
         return r < n_all ? r : n_all;
@@ -913,14 +918,16 @@ __host__ __device__ static inline ShardSpans shard_spans(int sym, int v, int V, 
         sp.a0 = row_of(v), sp.a1 = row_of(v + 1);
         return sp;
     }
-    int h = (V - 1) / 2;
-    if (!(V & 1) && v < V / 2) ++h;  // even count: the pair at distance V / 2 goes to the lower shard
-    const int s0 = v + 1 >= V ? 0 : v + 1;
-    if (s0 + h <= V) {
-        sp.a0 = row_of(s0), sp.a1 = row_of(s0 + h);
+    const int ring0 = (v / U) * U;  // first shard of the ring
+    const int u = v - ring0;
+    int h = (U - 1) / 2;
+    if (!(U & 1) && u < U / 2) ++h;  // even count: the pair at distance U / 2 goes to the lower shard
+    const int s0 = u + 1 >= U ? 0 : u + 1;
+    if (s0 + h <= U) {
+        sp.a0 = row_of(ring0 + s0), sp.a1 = row_of(ring0 + s0 + h);
     } else {
-        sp.a0 = row_of(s0), sp.a1 = row_of(V);
-        sp.b0 = 0, sp.b1 = row_of(s0 + h - V);
+        sp.a0 = row_of(ring0 + s0), sp.a1 = row_of(ring0 + U);
+        sp.b0 = row_of(ring0), sp.b1 = row_of(ring0 + s0 + h - U);
     }
     return sp;
 }
@@ -1074,7 +1081,7 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
     x_pos += tile_end - tile_begin;
     ColRange rng0 = a.rng[0], rng1 = a.rng[1];
     if (SYM != SYM_OFF) {
-        const ShardSpans sp = shard_spans(SYM, v, a.shards, a.row_blocks, a.rng[0].n);
+        const ShardSpans sp = shard_spans(SYM, v, a.shards, a.ring, a.row_blocks, a.rng[0].n);
         const float* z_all = a.rng[0].z;
         const int64_t base0 = a.rng[0].col_base;
         rng0 = ColRange{z_all + sp.a0 * a.ld, sp.a1 - sp.a0, base0 + sp.a0, (int)((sp.a1 - sp.a0 + BN - 1) / BN)};
@@ -1549,6 +1556,57 @@ __global__ __launch_bounds__(64 * FIN_ROWS) void topk_finalize_kernel(const u64*
 }
 
 // --------------------------------------------------------------------------
+// Between two symmetric sweeps: a show's candidates so far sit partly in its row lists and partly
+// in its column buffer, and neither alone tells how good its K-th neighbour already is.  One
+// wavefront per show ranks the keys of both that reach the show's current bound and raises the
+// bound to the K-th best of them, so that the next sweep starts from the bound a sweep of all
+// those columns in both orders would have left.
+// --------------------------------------------------------------------------
+constexpr int BMERGE_ROWS = 2;
+
+__global__ __launch_bounds__(64 * BMERGE_ROWS) void bound_merge_kernel(const u64* __restrict__ partial, int64_t nq, int k,
+                                                                      int splits, const unsigned* __restrict__ col_cnt,
+                                                                      const u64* __restrict__ col_buf, int col_cap,
+                                                                      int64_t q_row0, u64* __restrict__ bound) {
+    __shared__ u64 buf[BMERGE_ROWS][FIN_MAX_KEYS];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * BMERGE_ROWS + wave;
+    if (row >= nq) return;
+    u64* b = buf[wave];
+    const u64 floor_key = bound[row];
+    unsigned have = col_cnt[q_row0 + row];
+    if (have > (unsigned)col_cap) have = (unsigned)col_cap;
+    const int m_lists = splits * k;
+    const int m = m_lists + (int)have;
+    int packed = 0;
+    for (int i0 = 0; i0 < m && packed + 64 <= FIN_MAX_KEYS; i0 += 64) {
+        const int i = i0 + lane;
+        u64 key = 0ull;
+        if (i < m_lists) {
+            const int s = i / k;
+            key = partial[((int64_t)s * nq + row) * k + (i - s * k)];
+        } else if (i < m) {
+            key = col_buf[(q_row0 + row) * col_cap + (i - m_lists)];
+        }
+        const bool real = (uint32_t)key != 0u && key >= floor_key;
+        const u64 mask = __ballot(real);
+        if (real) b[packed + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = key;
+        packed += __builtin_popcountll(mask);
+    }
+    if (packed < k) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < packed; i += 64) {
+        const u64 me = b[i];
+        int rank = 0;
+        for (int j = 0; j < packed; ++j) rank += (b[j] > me) ? 1 : 0;
+        if (rank == k - 1)  // keys are distinct: exactly one has this rank
+            atomicMax(reinterpret_cast<unsigned long long*>(bound + row), (unsigned long long)me);
+    }
+}
+
+// --------------------------------------------------------------------------
 // Column-side buffers -> one more partial list per show.  One wavefront per show: entries that
 // reach the show's final bound are packed into LDS, ranked by counting, and the K best written
 // in the partial-list format (descending, empty slots = sentinel).
@@ -1984,8 +2042,20 @@ static int sym_shards(int row_blocks) {
     int shards = row_blocks / 8 < 32 ? row_blocks / 8 : 32;
     if (const char* e = getenv("TVBF_SYM_SHARDS")) shards = atoi(e);
     if (shards > row_blocks) shards = row_blocks;
-    if (shards > MAX_SHARDS) shards = MAX_SHARDS;
+    if (shards > MAX_TOP_SHARDS) shards = MAX_TOP_SHARDS;
     return shards;
+}
+
+// Second level: a shard with many row blocks is itself swept symmetrically, as a ring of this many
+// sub-shards (own columns, then half sweep inside the ring), before the half sweep over the shards.
+// 1 = the shard sweeps all its own columns in both orders.  TVBF_SYM_RING overrides (tuning / test aid).
+static int sym_ring(int row_blocks, int shards) {
+    if (shards < 1) return 1;
+    int ring = row_blocks / shards >= 16 ? 4 : 1;
+    if (const char* e = getenv("TVBF_SYM_RING")) ring = atoi(e);
+    if (ring > MAX_SHARDS / shards) ring = MAX_SHARDS / shards;
+    if (ring > row_blocks / shards) ring = row_blocks / shards;  // a sub-shard holds at least one row block
+    return ring < 2 ? 1 : ring;
 }
 
 // Work of an LDS-DMA launch (see TopkArgs): fills the shard table and the item count, returns the
@@ -1995,10 +2065,12 @@ static int sym_shards(int row_blocks) {
 // `gated`: a sweep that skips every row block without a flagged show.  Its few busy row blocks are
 // cut into about twelve stretches each, so that many workgroups share one block (with the usual
 // stretches a single flagged show would keep one workgroup busy for a whole row-block sweep).
-static int plan_items(TopkArgs* a, int sym, int64_t nq, int shards, int64_t n_all, int col_tiles, int cus,
+static int plan_items(TopkArgs* a, int sym, int64_t nq, int shards, int ring, int64_t n_all, int col_tiles, int cus,
                       int wg_per_cu, int max_slots, bool gated = false) {
     const int RB = (int)((nq + BM - 1) / BM);
     a->row_blocks = RB;
+    a->shards = shards;
+    a->ring = ring;
     int t_max = 0;
     if (sym == SYM_OFF) {
         a->n_sh = 1;
@@ -2011,7 +2083,7 @@ static int plan_items(TopkArgs* a, int sym, int64_t nq, int shards, int64_t n_al
         a->n_sh = shards;
         a->sh_prefix[0] = 0;
         for (int v = 0; v < shards; ++v) {
-            const ShardSpans sp = shard_spans(sym, v, shards, RB, n_all);
+            const ShardSpans sp = shard_spans(sym, v, shards, ring, RB, n_all);
             const int tiles = (int)((sp.a1 - sp.a0 + BN - 1) / BN) + (int)((sp.b1 - sp.b0 + BN - 1) / BN);
             a->sh_block0[v] = (int)(((int64_t)v * RB) / shards);
             const int blocks = (int)(((int64_t)(v + 1) * RB) / shards) - a->sh_block0[v];
@@ -2052,6 +2124,51 @@ static int plan_items(TopkArgs* a, int sym, int64_t nq, int shards, int64_t n_al
         }
         items = items * 3 / 4 > 0 ? items * 3 / 4 : 1;
     }
+}
+
+// The launches of a symmetric sweep of nq rows against themselves and the list slots each writes:
+//   one level   own columns of every shard (both orders), half sweep over the shards;
+//   two levels  own columns of every SUB-shard, half sweep inside every shard (a ring of sub-shards),
+//               then -- after bound_merge_kernel -- the half sweep over the shards.
+// `budget` list slots are shared out evenly over the launches.
+struct SymSweeps {
+    int n;                             // launches
+    int sym[3], shards[3], ring[3], slots[3];
+    TopkArgs work[3];                  // only the work tables (plan_items) are filled
+    int sweep_slots;                   // sum of slots[]
+};
+
+static bool plan_sym_sweeps(SymSweeps* sw, int64_t nq, int cus, int budget) {
+    const int row_blocks = (int)((nq + BM - 1) / BM);
+    const int shards = sym_shards(row_blocks);
+    if (shards < 2) return false;
+    const int ring = sym_ring(row_blocks, shards);
+    memset(sw, 0, sizeof(*sw));
+    if (ring > 1) {
+        sw->n = 3;
+        sw->sym[0] = SYM_DIAG, sw->shards[0] = shards * ring, sw->ring[0] = ring;
+        sw->sym[1] = SYM_HALF, sw->shards[1] = shards * ring, sw->ring[1] = ring;
+        sw->sym[2] = SYM_HALF, sw->shards[2] = shards, sw->ring[2] = shards;
+    } else {
+        sw->n = 2;
+        sw->sym[0] = SYM_DIAG, sw->shards[0] = shards, sw->ring[0] = shards;
+        sw->sym[1] = SYM_HALF, sw->shards[1] = shards, sw->ring[1] = shards;
+    }
+    for (int i = 0; i < sw->n; ++i) {
+        const int share = (budget - sw->sweep_slots) / (sw->n - i);
+        sw->slots[i] = plan_items(&sw->work[i], sw->sym[i], nq, sw->shards[i], sw->ring[i], nq, 0, cus, 2, share);
+        sw->sweep_slots += sw->slots[i];
+    }
+    return true;
+}
+
+// the work tables of a planned launch into the arguments of the launch
+static void take_work(TopkArgs* a, const TopkArgs& w) {
+    a->row_blocks = w.row_blocks, a->shards = w.shards, a->ring = w.ring;
+    a->items = w.items, a->n_sh = w.n_sh, a->total_tiles = w.total_tiles;
+    memcpy(a->sh_block0, w.sh_block0, sizeof(a->sh_block0));
+    memcpy(a->sh_tiles, w.sh_tiles, sizeof(a->sh_tiles));
+    memcpy(a->sh_prefix, w.sh_prefix, sizeof(a->sh_prefix));
 }
 
 // lists that no stretch writes (a row block cut fewer times than the most) must read as empty
@@ -2154,7 +2271,7 @@ size_t tvbf_topk_workspace_bytes(int64_t nq, int64_t n, int64_t d, int k) {
     if (topk_use_dma(d)) {
         TopkArgs a;
         memset(&a, 0, sizeof(a));
-        slots = plan_items(&a, SYM_OFF, nq, 1, 0, tiles_of(n), device_cus(), p.wg_per_cu, max_merge_slots(k));
+        slots = plan_items(&a, SYM_OFF, nq, 1, 1, 0, tiles_of(n), device_cus(), p.wg_per_cu, max_merge_slots(k));
     }
     return ws_bound_bytes(nq) + (size_t)slots * ws_slot_bytes(nq, k);
 }
@@ -2260,7 +2377,7 @@ static int accumulate_impl(const float* Zq, int64_t nq, int64_t q_row0, int64_t 
     int slots = p.splits;
     int64_t grid = (int64_t)p.row_blocks * p.splits;
     if (dma) {  // equal stretches of the line of tiles, one per resident workgroup
-        slots = plan_items(&a, SYM_OFF, nq, 1, 0, tiles, device_cus(), p.wg_per_cu, max_slots, gate != nullptr);
+        slots = plan_items(&a, SYM_OFF, nq, 1, 1, 0, tiles, device_cus(), p.wg_per_cu, max_slots, gate != nullptr);
         grid = a.items;
     }
     const size_t need = ws_bound_bytes(nq) + (size_t)(slot0 + slots) * ws_slot_bytes(nq, k);
@@ -2373,26 +2490,22 @@ int tvbf_topk_accumulate_sym_f32(const float* Zq, int64_t nq, int64_t q_row0, in
     int half_cap = 0;
     const int col_lds = colside_queue(k, d, &lds_half, &half_cap);
     const int row_blocks = (int)((nq + BM - 1) / BM);
-    int shards = sym_shards(row_blocks);
-    if (!col_lds || shards < 2)
-        return fail(TVBF_E_BAD_SHAPE, "the symmetric sweep needs d %% 64 == 0 and at least 16 row blocks");
-    if (shards > MAX_SHARDS) shards = MAX_SHARDS;
     const int cus = device_cus();
-    int budget = max_slots - 1;  // one slot is the reduced column side
+    const int budget = max_slots - 1;  // one slot is the reduced column side
     if (budget < 2) return fail(TVBF_E_BAD_ARG, "the symmetric sweep needs at least 3 slots");
+    SymSweeps sw;
+    if (!col_lds || !plan_sym_sweeps(&sw, nq, cus, budget))
+        return fail(TVBF_E_BAD_SHAPE, "the symmetric sweep needs d %% 64 == 0 and at least 16 row blocks");
     const size_t lds_diag = topk_lds_bytes(k, d);
-    TopkArgs a, ah;
-    memset(&a, 0, sizeof(a));
-    const int s_diag = plan_items(&a, SYM_DIAG, nq, shards, nq, 0, cus, 2, budget / 2);
-    ah = a;
-    const int s_half = plan_items(&ah, SYM_HALF, nq, shards, nq, 0, cus, 2, budget - s_diag);
-    const int total = s_diag + s_half + 1;
+    const int total = sw.sweep_slots + 1;
     const size_t need = ws_bound_bytes(nq) + (size_t)(slot0 + total) * ws_slot_bytes(nq, k);
     if (workspace_bytes < need) return fail(TVBF_E_BAD_SHAPE, "workspace must be >= %zu bytes", need);
 
     hipStream_t st = (hipStream_t)stream;
     char* ws = reinterpret_cast<char*>(workspace);
     char* cst = reinterpret_cast<char*>(colside->state);
+    TopkArgs a;
+    memset(&a, 0, sizeof(a));
     a.zq = Zq;
     a.rng[0] = ColRange{Zq, nq, q_row0, tiles_of(nq)};
     a.rng[1] = ColRange{Zq, 0, 0, 0};
@@ -2402,12 +2515,10 @@ int tvbf_topk_accumulate_sym_f32(const float* Zq, int64_t nq, int64_t q_row0, in
     a.ld = ld;
     a.d = (int)d;
     a.k = k;
-    a.cap = topk_cap(k, d);
     a.row_blocks = row_blocks;
     a.col_tiles = tiles_of(nq);
     a.min_similarity = min_similarity;
     a.exclude_self = exclude_self;
-    a.shards = shards;
     a.col_bound = a.bound - q_row0;  // indexed by global row; only this block's rows are ever read
     a.overflow = reinterpret_cast<unsigned*>(cst);
     a.col_cnt = reinterpret_cast<unsigned*>(cst + cs_cnt_off(colside->n_total));
@@ -2426,30 +2537,38 @@ int tvbf_topk_accumulate_sym_f32(const float* Zq, int64_t nq, int64_t q_row0, in
                                      : reinterpret_cast<const void*>(cosine_topk_dma_kernel<false, SYM_HALF>);
     HIP_TRY(hipFuncSetAttribute(k_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag));
     HIP_TRY(hipFuncSetAttribute(k_half, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_half));
-    clear_slots(lists, nq, k, s_diag + s_half, st);
-    a.partial = lists;
-    if (a.items > 0 && list_global)
-        hipLaunchKernelGGL((cosine_topk_dma_kernel<true, SYM_DIAG>), dim3((unsigned)a.items), dim3(TOPK_THREADS),
-                           lds_diag, st, a);
-    else if (a.items > 0)
-        hipLaunchKernelGGL((cosine_topk_dma_kernel<false, SYM_DIAG>), dim3((unsigned)a.items), dim3(TOPK_THREADS),
-                           lds_diag, st, a);
-    // the half sweep: same arguments, its own shard table, the lists capped for the column queue
-    a.items = ah.items, a.n_sh = ah.n_sh, a.total_tiles = ah.total_tiles;
-    memcpy(a.sh_block0, ah.sh_block0, sizeof(a.sh_block0));
-    memcpy(a.sh_tiles, ah.sh_tiles, sizeof(a.sh_tiles));
-    memcpy(a.sh_prefix, ah.sh_prefix, sizeof(a.sh_prefix));
-    a.partial = lists + (size_t)s_diag * nq * k;
-    a.cap = half_cap;
-    if (a.items > 0 && list_global)
-        hipLaunchKernelGGL((cosine_topk_dma_kernel<true, SYM_HALF>), dim3((unsigned)a.items), dim3(TOPK_THREADS),
-                           lds_half, st, a);
-    else if (a.items > 0)
-        hipLaunchKernelGGL((cosine_topk_dma_kernel<false, SYM_HALF>), dim3((unsigned)a.items), dim3(TOPK_THREADS),
-                           lds_half, st, a);
+    clear_slots(lists, nq, k, sw.sweep_slots, st);
+    int done = 0;  // list slots written so far
+    for (int i = 0; i < sw.n; ++i) {
+        if (i == 2)  // the shards' own blocks are complete: bounds from row lists and column buffers together
+            hipLaunchKernelGGL(bound_merge_kernel, dim3((unsigned)((nq + BMERGE_ROWS - 1) / BMERGE_ROWS)),
+                               dim3(64 * BMERGE_ROWS), 0, st, lists, nq, k, done, a.col_cnt, a.col_buf, a.col_cap,
+                               q_row0, a.bound);
+        take_work(&a, sw.work[i]);
+        a.partial = lists + (size_t)done * nq * k;
+        done += sw.slots[i];
+        if (a.items <= 0) continue;
+        if (sw.sym[i] == SYM_DIAG) {
+            a.cap = topk_cap(k, d);
+            if (list_global)
+                hipLaunchKernelGGL((cosine_topk_dma_kernel<true, SYM_DIAG>), dim3((unsigned)a.items),
+                                   dim3(TOPK_THREADS), lds_diag, st, a);
+            else
+                hipLaunchKernelGGL((cosine_topk_dma_kernel<false, SYM_DIAG>), dim3((unsigned)a.items),
+                                   dim3(TOPK_THREADS), lds_diag, st, a);
+        } else {  // the lists capped for the column queue
+            a.cap = half_cap;
+            if (list_global)
+                hipLaunchKernelGGL((cosine_topk_dma_kernel<true, SYM_HALF>), dim3((unsigned)a.items),
+                                   dim3(TOPK_THREADS), lds_half, st, a);
+            else
+                hipLaunchKernelGGL((cosine_topk_dma_kernel<false, SYM_HALF>), dim3((unsigned)a.items),
+                                   dim3(TOPK_THREADS), lds_half, st, a);
+        }
+    }
     hipLaunchKernelGGL(col_reduce_kernel, dim3((unsigned)((nq + COLRED_ROWS - 1) / COLRED_ROWS)), dim3(64 * COLRED_ROWS),
                        0, st, a.col_cnt, a.col_buf, a.col_cap, a.col_bound, nq, k, min_similarity,
-                       lists + (size_t)(s_diag + s_half) * nq * k, q_row0);
+                       lists + (size_t)done * nq * k, q_row0);
     HIP_TRY(hipGetLastError());
     *slots_used = total;
     return TVBF_OK;
@@ -2587,8 +2706,10 @@ int tvbf_cosine_topk_f32(const float* Zq, int64_t nq, int64_t q_row0, const floa
 // ---- symmetric whole-catalogue sweep ----
 // Z Z^T is symmetric bit for bit, so every pair of different shows needs computing only once.
 // The row blocks are grouped into `shards`:
-//   1. every shard against its own columns (row side only) -- 1 / shards of the work, and every
-//      show gets a bound on its K-th score from a sizeable sample of the catalogue;
+//   1. every shard against its own columns -- 1 / shards of the work, and every show gets a bound
+//      on its K-th score from a sizeable sample of the catalogue.  A small shard does it in both
+//      orders, row side only; a shard of 16 or more row blocks is itself swept symmetrically as a
+//      ring of sub-shards (plan_sym_sweeps), after which bound_merge_kernel derives the bounds;
 //   2. every shard against the half of the other shards that follows it cyclically, both sides:
 //      the row side feeds the lists as usual, the column side appends the scores that reach the
 //      bound of their column's show to that show's buffer (first into an LDS queue, drained with
@@ -2617,10 +2738,10 @@ static SymPlan make_sym_plan(int64_t n, int64_t d, int k) {
     const int slots = max_merge_slots(k);
     TopkArgs a;
     memset(&a, 0, sizeof(a));
-    const int s_diag = plan_items(&a, SYM_DIAG, n, shards, n, 0, cus, 2, (slots - 1) / 2);
-    const int s_half = plan_items(&a, SYM_HALF, n, shards, n, 0, cus, 2, slots - 1 - s_diag);
-    sp.s_sym = s_diag + s_half + 1;
-    sp.s_full = plan_items(&a, SYM_OFF, n, 1, 0, tiles_of(n), cus, 2, slots < 16 ? slots : 16, true);
+    SymSweeps sw;
+    if (!plan_sym_sweeps(&sw, n, cus, slots - 1)) return sp;
+    sp.s_sym = sw.sweep_slots + 1;
+    sp.s_full = plan_items(&a, SYM_OFF, n, 1, 1, 0, tiles_of(n), cus, 2, slots < 16 ? slots : 16, true);
     sp.col_cap = COL_CAP_MAX;
     if (const char* e = getenv("TVBF_SYM_COL_CAP")) sp.col_cap = atoi(e);  // tuning / test aid
     if (sp.col_cap < 1) sp.col_cap = 1;
