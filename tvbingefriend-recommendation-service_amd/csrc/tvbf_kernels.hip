@@ -1490,6 +1490,12 @@ constexpr int FIN_MAX_KEYS = 2048;  // partial lists per row * k
 
 constexpr int FIN_ROWS = 2;  // rows (wavefronts) per workgroup
 
+// LDS of the merge kernel: room for the keys of the longer list set (normal or alternative) per row
+static size_t fin_lds_bytes(int normal_lists, int alt_lists, int k) {
+    const int lists = normal_lists > alt_lists ? normal_lists : alt_lists;
+    return (size_t)FIN_ROWS * (size_t)(lists > 0 ? lists : 1) * (size_t)k * sizeof(u64);
+}
+
 // `gate` (may be null) points at the per-row overflow flags of these nq rows: a flagged row merges
 // the lists [alt_first, alt_first + alt_splits) -- the plain re-run of its row block -- instead.
 // `bound` (may be null): the rows' bound keys.  Each is the K-th best of some set of real candidates
@@ -1502,17 +1508,19 @@ __global__ __launch_bounds__(64 * FIN_ROWS) void topk_finalize_kernel(const u64*
                                                             const unsigned* __restrict__ gate, int alt_first,
                                                             int alt_splits, const u64* __restrict__ extra,
                                                             int n_extra, int64_t extra_stride) {
-    __shared__ u64 buf[FIN_ROWS][FIN_MAX_KEYS];
+    extern __shared__ u64 fin_keys[];  // FIN_ROWS x (keys of the longer of the two list sets): see fin_lds_bytes()
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int64_t row = (int64_t)blockIdx.x * FIN_ROWS + wave;
     if (row >= nq) return;
+    const int normal = splits + n_extra;
+    const int widest = (gate && alt_splits > normal) ? alt_splits : normal;
+    u64* b = fin_keys + (size_t)wave * (size_t)(widest * k);
     if (gate && gate[row] != 0u) {
         partial += (int64_t)alt_first * nq * k;
         splits = alt_splits;
         n_extra = 0;
     }
-    u64* b = buf[wave];
     const int m = (splits + n_extra) * k;
     const u64 floor_key = bound ? bound[row] : 0ull;
     // gather the non-empty keys of all partial lists, packed (most slots of late splits are empty
@@ -1562,13 +1570,14 @@ __global__ __launch_bounds__(64 * FIN_ROWS) void topk_finalize_kernel(const u64*
 // bound to the K-th best of them, so that the next sweep starts from the bound a sweep of all
 // those columns in both orders would have left.
 // --------------------------------------------------------------------------
-constexpr int BMERGE_ROWS = 2;
+constexpr int BMERGE_ROWS = 4;
+constexpr int BMERGE_KEYS = 512;  // keys at or above the bound that are ranked (>= TVBF_MAX_K)
 
 __global__ __launch_bounds__(64 * BMERGE_ROWS) void bound_merge_kernel(const u64* __restrict__ partial, int64_t nq, int k,
                                                                       int splits, const unsigned* __restrict__ col_cnt,
                                                                       const u64* __restrict__ col_buf, int col_cap,
                                                                       int64_t q_row0, u64* __restrict__ bound) {
-    __shared__ u64 buf[BMERGE_ROWS][FIN_MAX_KEYS];
+    __shared__ u64 buf[BMERGE_ROWS][BMERGE_KEYS];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int64_t row = (int64_t)blockIdx.x * BMERGE_ROWS + wave;
@@ -1580,7 +1589,8 @@ __global__ __launch_bounds__(64 * BMERGE_ROWS) void bound_merge_kernel(const u64
     const int m_lists = splits * k;
     const int m = m_lists + (int)have;
     int packed = 0;
-    for (int i0 = 0; i0 < m && packed + 64 <= FIN_MAX_KEYS; i0 += 64) {
+    // (a full buffer ends the gathering: the K-th best of a subset is a valid bound as well)
+    for (int i0 = 0; i0 < m && packed + 64 <= BMERGE_KEYS; i0 += 64) {
         const int i = i0 + lane;
         u64 key = 0ull;
         if (i < m_lists) {
@@ -2649,7 +2659,8 @@ int tvbf_topk_finish_ex(int64_t nq, int k, int slots, const uint64_t* extra, int
         return fail(TVBF_E_BAD_SHAPE, "workspace smaller than the slots it is said to hold");
     if (nq == 0) return TVBF_OK;
     const char* ws = reinterpret_cast<const char*>(workspace);
-    hipLaunchKernelGGL(topk_finalize_kernel, dim3((unsigned)((nq + FIN_ROWS - 1) / FIN_ROWS)), dim3(64 * FIN_ROWS), 0,
+    hipLaunchKernelGGL(topk_finalize_kernel, dim3((unsigned)((nq + FIN_ROWS - 1) / FIN_ROWS)), dim3(64 * FIN_ROWS),
+                       fin_lds_bytes(slots + n_extra, gate ? alt_slots : 0, k),
                        (hipStream_t)stream, reinterpret_cast<const u64*>(ws),
                        reinterpret_cast<const u64*>(ws + ws_bound_bytes(nq)), nq, k, slots, out_idx, out_score,
                        out_count, gate, alt_first, alt_slots, reinterpret_cast<const u64*>(extra), n_extra,
@@ -2669,8 +2680,8 @@ static int finish_lists(int64_t nq, int k, int slots, int32_t* out_idx, float* o
         return fail(TVBF_E_BAD_SHAPE, "workspace smaller than the slots it is said to hold");
     if (nq == 0) return TVBF_OK;
     const char* ws = reinterpret_cast<const char*>(workspace);
-    hipLaunchKernelGGL(topk_finalize_kernel, dim3((unsigned)((nq + FIN_ROWS - 1) / FIN_ROWS)), dim3(64 * FIN_ROWS), 0,
-                       (hipStream_t)stream, with_bounds ? reinterpret_cast<const u64*>(ws) : (const u64*)nullptr,
+    hipLaunchKernelGGL(topk_finalize_kernel, dim3((unsigned)((nq + FIN_ROWS - 1) / FIN_ROWS)), dim3(64 * FIN_ROWS),
+                       fin_lds_bytes(slots, 0, k), (hipStream_t)stream, with_bounds ? reinterpret_cast<const u64*>(ws) : (const u64*)nullptr,
                        reinterpret_cast<const u64*>(ws + ws_bound_bytes(nq)), nq, k, slots, out_idx, out_score,
                        out_count, (const unsigned*)nullptr, 0, 0, (const u64*)nullptr, 0, (int64_t)0);
     HIP_TRY(hipGetLastError());
