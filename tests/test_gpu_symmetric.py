@@ -272,6 +272,21 @@ def test_symmetric_sharded_job_equals_plain(pkg, device, n, world):
         _assert_same(got, plain, f"n={n} world={world} k={k}")
 
 
+@pytest.mark.parametrize("n,world,shards,ring", [(9000, 2, 4, 2), (9100, 4, 2, 3), (13000, 3, 3, 4)])
+def test_symmetric_sharded_job_two_levels(pkg, device, monkeypatch, n, world, shards, ring):
+    """Ranks whose own blocks are swept on two levels (as blocks of 16 or more row blocks per
+    shard are by default): same lists as the single-GPU plain sweep."""
+    from tvbingefriend_recommendation_service_amd import engine
+
+    z, _, _ = _z_hybrid(device, n, seed=600 + n + world)
+    plain = engine.cosine_topk(z, 20, 0.1)
+    monkeypatch.setenv("TVBF_SYM_SHARDS", str(shards))
+    monkeypatch.setenv("TVBF_SYM_RING", str(ring))
+    got, flag = _lockstep_ranks(device, z, n, world, 20, 0.1)
+    assert flag == 0
+    _assert_same(got, plain, f"n={n} world={world} shards={shards} ring={ring}")
+
+
 def test_symmetric_sharded_job_overflow(pkg, device):
     """Column buffers of one entry overflow on every rank: all ranks re-run plainly, same lists."""
     from tvbingefriend_recommendation_service_amd import engine
