@@ -151,7 +151,8 @@ int tvbf_cosine_topk_f32(const float* Zq, int64_t nq, int64_t q_row0, const floa
  * scripts/populate_database.py:170-218 over all shows) computing every pair of shows ONCE.
  * score(i, j) and score(j, i) are the same products summed in the same order, so the score
  * matrix is symmetric bit for bit and the result equals tvbf_cosine_topk_f32's exactly; only
- * about half of it (plus 1/16 for seeding the bounds) is computed.
+ * about half of it is computed (0.50-0.53 of the ordered pairs: blocks of rows near the
+ * diagonal are computed in both orders to seed the bounds).
  *
  *   d           multiple of 64;  n at least 16 blocks of 128 rows (more than 1920 shows)
  *   workspace   >= tvbf_cosine_topk_sym_workspace_bytes(n, d, k) bytes, which returns 0 when
