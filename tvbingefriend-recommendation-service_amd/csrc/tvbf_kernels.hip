@@ -202,6 +202,7 @@ struct TopkArgs {
     u64* col_buf;               // [shows][col_cap] keys (score, global row of the QUERY side)
     int col_cap, col_lds;       // entries per show; entries of the workgroup's LDS queue
     int col_drain;              // queue length at which it is drained between two tiles
+    unsigned col_window;        // appended entries after which a show's bound is refreshed (64, 128 or 256)
     unsigned* overflow;         // [0]: a buffer was full somewhere; [OVF_SHOWS + show]: this show's buffer was
     const unsigned* gate;       // plain sweeps (null: always run): the same layout, indexed by global row --
                                 // only row blocks holding a flagged show are swept
@@ -932,7 +933,7 @@ __host__ __device__ static inline ShardSpans shard_spans(int sym, int v, int V, 
     return sp;
 }
 
-constexpr unsigned COL_WINDOW = 256;  // appended entries after which a show's bound is refreshed
+constexpr unsigned COL_WINDOW_MAX = 256;  // most appended entries after which a show's bound is refreshed (TopkArgs::col_window)
 
 // Returns the position the key went to (>= col_cap: dropped).  Entries are written through to
 // device scope so that a refresh on another XCD can see them.
@@ -949,24 +950,30 @@ __device__ static inline unsigned col_append(const TopkArgs& a, unsigned rowg, u
 
 // The column side has no list that adapts as candidates arrive, so a show whose K-th score is
 // shared by thousands of shows (metadata-only matches, identical shows) would take every one of
-// them with a lower index than its current K-th.  Whenever a show's buffer has grown by another
-// COL_WINDOW entries, the wave that appended the last of them ranks that window (the entries
-// already visible; buffers start zeroed and 0 is no key) and raises the show's bound key to the
-// window's K-th best: the K-th best of any set of real candidates is a valid lower bound.
-__device__ static inline void col_refresh_bound(const TopkArgs& a, unsigned rowg, unsigned w0, u64* scr, int lane) {
-    const u64* src = a.col_buf + (int64_t)rowg * a.col_cap + w0;
+// them with a lower index than its current K-th.  When a show's buffer reaches 256 entries (few
+// shows of an ordinary catalogue do), and then whenever it has grown by another col_window
+// entries (64, 128 or 256: the smallest that holds 2 K keys -- every window cuts the share of
+// ties that still pass to about K / window of what it was, so small windows converge in far
+// fewer entries), the wave that appended the last of them ranks that window (the entries already visible; buffers start zeroed and 0 is
+// no key) and raises the show's bound key to the window's K-th best: the K-th best of any set of
+// real candidates is a valid lower bound.
+__device__ static inline void col_refresh_bound(const TopkArgs& a, unsigned rowg, unsigned end, u64* scr, int lane) {
+    // the first window is the first COL_WINDOW_MAX entries, the later ones col_window entries each
+    const unsigned window = end == COL_WINDOW_MAX ? COL_WINDOW_MAX : a.col_window;
+    const u64* src = a.col_buf + (int64_t)rowg * a.col_cap + (end - window);
+    const int per_lane = (int)window / 64;  // 1, 2 or 4 keys per lane
     u64 my[4];
     int rk[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        my[u] = __hip_atomic_load(src + lane + 64 * u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        scr[lane + 64 * u] = my[u];
+        my[u] = u < per_lane ? __hip_atomic_load(src + lane + 64 * u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        if (u < per_lane) scr[lane + 64 * u] = my[u];
         rk[u] = 0;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #pragma nounroll
-    for (int i = 0; i < (int)COL_WINDOW; i += 4) {
+    for (int i = 0; i < (int)window; i += 4) {
         u64 o[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) o[t] = scr[i + t];  // same address in every lane: LDS broadcast
@@ -983,6 +990,11 @@ __device__ static inline void col_refresh_bound(const TopkArgs& a, unsigned rowg
     __builtin_amdgcn_wave_barrier();
 }
 
+// whether the entry appended at position p completes a window of its show's buffer
+__device__ static inline bool col_window_ends(const TopkArgs& a, unsigned p) {
+    return p < (unsigned)a.col_cap && p + 1u >= COL_WINDOW_MAX && (p + 1u - COL_WINDOW_MAX) % a.col_window == 0u;
+}
+
 // Drain of the workgroup's queue: every thread appends its share; waves then refresh the bounds
 // of the shows whose buffers completed a window.
 __device__ static inline void col_drain(const TopkArgs& a, const unsigned* lrowg, const u64* lkey, unsigned count,
@@ -994,13 +1006,13 @@ __device__ static inline void col_drain(const TopkArgs& a, const unsigned* lrowg
         if (i < count) {
             rowg = lrowg[i];
             p = col_append(a, rowg, lkey[i]);
-            crossed = p < (unsigned)a.col_cap && (p + 1u) % COL_WINDOW == 0u;
+            crossed = col_window_ends(a, p);
         }
         u64 todo = __ballot(crossed);
         while (todo) {
             const int l = (int)__builtin_ctzll(todo);
             todo &= todo - 1ull;
-            col_refresh_bound(a, __shfl(rowg, l, 64), __shfl(p, l, 64) + 1u - COL_WINDOW, scr, lane);
+            col_refresh_bound(a, __shfl(rowg, l, 64), __shfl(p, l, 64) + 1u, scr, lane);
         }
     }
 }
@@ -1384,8 +1396,7 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
                                 lrowg[pos] = rowg;
                             } else {  // queue full: straight to the show's buffer
                                 const unsigned p = col_append(a, rowg, key);
-                                if (p < (unsigned)a.col_cap && (p + 1u) % COL_WINDOW == 0u)
-                                    pend = true, pend_row = rowg, pend_w0 = p + 1u - COL_WINDOW;
+                                if (col_window_ends(a, p)) pend = true, pend_row = rowg, pend_w0 = p + 1u;
                             }
                         }
                     }
@@ -2224,6 +2235,18 @@ static int colside_drain_at(int col_lds) {
     return at < 1 ? 1 : at;
 }
 
+// Entries a show's buffer grows by between two refreshes of its bound: the smallest of 64 / 128 /
+// 256 that holds 2 K keys (TVBF_COL_WINDOW: tuning aid; at least K keys are needed to rank a K-th).
+static unsigned colside_window(int k) {
+    unsigned w = 2 * k <= 64 ? 64u : 2 * k <= 128 ? 128u : COL_WINDOW_MAX;
+    if (const char* e = getenv("TVBF_COL_WINDOW")) {
+        const int v = atoi(e);
+        if (v == 64 || v == 128 || v == 256) w = (unsigned)v;
+    }
+    while (w < (unsigned)k) w *= 2;
+    return w;
+}
+
 // workspace = [nq bound keys, padded to 16 bytes][slot 0: nq x k keys][slot 1] ...
 static size_t ws_bound_bytes(int64_t nq) { return ((size_t)nq * 8 + 15) / 16 * 16; }
 static size_t ws_cnt_bytes(int64_t n) { return ((size_t)n * 4 + 15) / 16 * 16; }  // 32-bit counters
@@ -2430,6 +2453,7 @@ static int accumulate_impl(const float* Zq, int64_t nq, int64_t q_row0, int64_t 
         a.col_cap = cs->cap;
         a.col_lds = col_lds;
         a.col_drain = colside_drain_at(col_lds);
+        a.col_window = colside_window(k);
         a.cap = col_list_cap;
     }
 #ifdef TVBF_DIAG_TIMELINE
@@ -2536,6 +2560,7 @@ int tvbf_topk_accumulate_sym_f32(const float* Zq, int64_t nq, int64_t q_row0, in
     a.col_cap = colside->cap;
     a.col_lds = col_lds;
     a.col_drain = colside_drain_at(col_lds);
+    a.col_window = colside_window(k);
 #ifdef TVBF_DIAG_TIMELINE
     if (const char* e = getenv("TVBF_DIAG_BUF")) a.gram = reinterpret_cast<float*>(strtoull(e, nullptr, 0));
 #endif
