@@ -190,8 +190,49 @@ def end_to_end(x_host, offsets, scales, k, min_similarity, dev):
     }
 
 
+def launch_ranks(args) -> int:
+    """`--gpus N` without a launcher: start N fresh rank processes of this script (rank r on GPU r,
+    rendezvous on 127.0.0.1) and wait for them.  Runs before anything here has touched the GPU --
+    the children initialise it, this process never does.  Rank 0 prints the JSON line on the
+    inherited stdout.  When a rank fails the others are ended (by PID) and its code is returned."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env))
+    code = 0
+    while any(p.poll() is None for p in procs):
+        failed = [p for p in procs if p.poll() not in (None, 0)]
+        if failed:
+            code = failed[0].returncode
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            deadline = time.time() + 10
+            for p in procs:
+                try:
+                    p.wait(timeout=max(0.1, deadline - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        time.sleep(0.1)
+    for p in procs:
+        rc = p.wait()
+        if rc and not code:
+            code = rc
+    return code
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -203,7 +244,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher must start --gpus ranks")
+    if args.backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit(f"--gpus {world} with the nccl backend needs {world} GPUs, {torch.cuda.device_count()} "
+                         "visible (--backend gloo rehearses several ranks on one GPU)")
     dev = torch.device(f"cuda:{local_rank % torch.cuda.device_count()}")
     torch.cuda.set_device(dev)
     if world > 1:
@@ -237,16 +281,39 @@ def main():
         raise SystemExit("--sweep symmetric: row length a multiple of 64, more than 1920 shows, and for several "
                          "GPUs a K small enough that one merge takes all lists")
     symmetric = sym_bytes > 0
+
+    def max_over_ranks(v):
+        t = torch.tensor([v], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # The route is decided here, before any collective of a step: the shape test above is the same
+    # on every rank, the buffers of the symmetric sharded route are allocated now, and one flag is
+    # reduced over the ranks.  After this point an exception inside a step ends the job.
     side = None
     if symmetric and world == 1:
         workspace = torch.empty((sym_bytes + 15) // 16 * 2, dtype=torch.int64, device=dev)
-    elif symmetric:  # sharded: lists of the own, half and (gated) plain sweeps; column buffers of all shows
-        slots = 96
-        ws_bytes = int(native.load().tvbf_topk_workspace_bytes_for_slots(max(nq, 1), args.k, slots))
-        workspace = torch.empty((ws_bytes + 15) // 16 * 2, dtype=torch.int64, device=dev)
-        side = engine.ColumnSide(shard.padded_total, dev, cap=1024)
+    elif world > 1:
+        failed = 0.0
+        if symmetric:  # lists of the own, half and (gated) plain sweeps; column buffers of all shows
+            try:
+                sym_ws_bytes = int(native.load().tvbf_topk_workspace_bytes_for_slots(max(nq, 1), args.k, 96))
+                sym_workspace = torch.empty((sym_ws_bytes + 15) // 16 * 2, dtype=torch.int64, device=dev)
+                side = engine.ColumnSide(shard.padded_total, dev, cap=1024)
+                torch.cuda.synchronize()
+            except Exception as e:  # noqa: BLE001
+                failed = 1.0
+                print(f"[rank {rank}] buffers of the symmetric sharded route: {e!r}", file=sys.stderr, flush=True)
+        if max_over_ranks(failed) > 0.0:
+            symmetric, side = False, None
+            if rank == 0:
+                print("symmetric sharded route not available on every rank: plain sharded route", file=sys.stderr,
+                      flush=True)
+        elif symmetric:
+            slots, workspace = 96, sym_workspace
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     kernel_ms = []
+    tiles_step = [0]  # 128 x 128 score tiles the sweeps of one step compute on this rank
     own, after, before = sharding.column_pieces(shard)
 
     class HostGather:
@@ -275,6 +342,7 @@ def main():
             if timed:
                 ev[0].record()
             engine.cosine_topk_symmetric(z_shard, args.k, min_sim, n=nq, workspace=workspace, out=out)
+            tiles_step[0] = engine.symmetric_tiles(nq, dev)
         elif symmetric:
             job = sharding.SymmetricShardJob(z_shard, shard, args.k, min_sim, slots=slots, workspace=workspace,
                                              colside=side)
@@ -288,6 +356,7 @@ def main():
             flag = sharding.reduce_flag(job.flag)
             recv = sharding.exchange_lists(send)
             job.finish(z_all, recv, flag, out)
+            tiles_step[0] = job.tiles
         else:
             session = engine.TopkSession(z_shard, nq, shard.row0, args.k, min_sim, slots=slots, workspace=workspace)
             if timed:
@@ -297,6 +366,7 @@ def main():
                 work.wait()
                 session.accumulate((z_all[after[0]:], after[1], after[0]), (z_all, before[1], before[0]))
             session.finish(out)
+            tiles_step[0] = session.tiles
         if timed:
             ev[1].record()
         comp = engine.component_scores(z_all, offsets, scales, out.idx, q_row0=shard.row0, n=args.n)
@@ -311,25 +381,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def max_over_ranks(v):
-        t = torch.tensor([v], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
-
     if symmetric and world > 1:
-        # untimed priming step of the symmetric sharded route (it uses collectives the plain route
-        # does not: int64 all-gather and all-to-all, int32 max-reduction); if it raises, all ranks
-        # go on with the plain sharded route together
-        ok = 1.0
-        try:
-            step(False)
-            torch.cuda.synchronize()
-        except Exception as e:  # noqa: BLE001
-            ok = 0.0
-            print(f"[rank {rank}] symmetric sharded route failed ({e!r}); falling back to the plain route",
-                  file=sys.stderr, flush=True)
-        if -max_over_ranks(-ok) < 1.0:
-            symmetric = False
+        step(False)  # untimed: the first use of the int64 all-gather, the all-to-all and the max-reduction
     for _ in range(args.warmup):
         step(False)
     barrier()
@@ -357,9 +410,16 @@ def main():
             raise SystemExit(3)
 
     pairs = float(args.n) * float(args.n) * args.steps
-    # dominant kernel: 2*D flops per ordered pair, nq*n pairs per launch on this rank
+    # dominant kernel: 2*D flops per ordered pair, nq*n pairs per launch on this rank.  `achieved` is
+    # what the matrix pipe really executed: the library's count of 128 x 128 score tiles of the
+    # step's sweeps x 2 * 128 * 128 * ld flops (zero padding columns of Z included, they are
+    # multiplied like any other), over the HIP-event time around them.
     per_rank_rows = shard.per_rank if world > 1 else nq
-    achieved = 2.0 * per_rank_rows * args.n * args.d / (kernel_avg_ms * 1e-3) / 1e12
+    algorithmic = 2.0 * per_rank_rows * args.n * args.d
+    executed = 2.0 * tiles_step[0] * 128.0 * 128.0 * ld
+    achieved = executed / (kernel_avg_ms * 1e-3) / 1e12
+    effective = algorithmic / (kernel_avg_ms * 1e-3) / 1e12
+    plain_tiles = ((nq + 127) // 128) * ((args.n + 127) // 128)
     workload = (f"N={args.n} shows x D={args.d} fp32 ({'genre32|text%d|meta32 hybrid-like' % (args.d - 64) if args.data == 'hybrid' else 'dense gaussian'}), "
                 f"K={args.k}, min_similarity={min_sim}")
     traffic = None
@@ -370,18 +430,7 @@ def main():
             traffic = json.loads(tf.read_text()).get(key)
         except Exception:
             traffic = None
-    # share of the ordered pairs the sweeps really compute (1 for the plain sweep): every pair of
-    # different shards is computed once; a shard's own block, 1/V of all pairs, is computed in both
-    # orders, or -- a shard of 16 or more row blocks -- as a ring of U = 4 sub-shards in the same way
-    share = 1.0
-    if symmetric and world == 1:
-        row_blocks = (nq + 127) // 128
-        v = max(2, min(32, row_blocks // 8))
-        u = 4 if row_blocks // v >= 16 else 1
-        own = 1.0 if u == 1 else 1.0 / u + (u - 1) / (2.0 * u)
-        share = own / v + (v - 1) / (2.0 * v)
-    elif symmetric:
-        share = None  # per rank: own block symmetric + (world - 1) / 2 foreign blocks; see the design notes
+    share = tiles_step[0] / plain_tiles if plain_tiles else None  # of the ordered pairs, really computed
     line = {
         "metric": "show-pairs/sec (all-pairs cosine + per-row top-K)",
         "value": pairs / elapsed,
@@ -399,7 +448,7 @@ def main():
                    "parallelism": (f"row-shard x{world} + all-gather ({args.backend})"
                                    + (" + all-to-all of column-side lists" if symmetric else "")) if world > 1 else "single GPU",
                    "sweep": "symmetric: every unordered pair of shows computed once, both shows' lists fed from it; "
-                            "flops counted as 2*N^2*D all the same" if symmetric else "plain: every ordered pair computed"},
+                            "roofline.achieved counts the flops executed" if symmetric else "plain: every ordered pair computed"},
         "topk_build_time_s": elapsed / args.steps,
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
@@ -412,9 +461,11 @@ def main():
                                 "cosine_topk_dma_kernel<false, 0> (HIP events also span the 4 us bound fill and the "
                                 "0.3 ms list merge of the same call)"), "kernel_ms": kernel_avg_ms,
                      "pairs_computed_share": share,
-                     "executed_frac": None if share is None else achieved * share / FP32_MFMA_PEAK_TFLOPS,
-                     "note": "achieved and frac count 2*D flops for every ordered pair (the work the path is "
-                             "specified by); executed_frac = the flops really executed over the peak"},
+                     "algorithmic_flops": algorithmic, "executed_flops": executed,
+                     "effective_vs_2N2D": effective, "effective_frac_vs_2N2D": effective / FP32_MFMA_PEAK_TFLOPS,
+                     "note": "achieved and frac = flops the MFMA pipe executed (tile count from the library) over "
+                             "the HIP-event time, a physical pipe fraction; effective_vs_2N2D credits 2*D flops "
+                             "for every ordered pair, computed or not (the work the path is specified by)"},
     }
     x_host = None  # --no-cpu-baseline skips both host-side legs (profiling runs)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

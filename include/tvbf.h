@@ -167,6 +167,14 @@ int tvbf_cosine_topk_sym_f32(const float* Z, int64_t n, int64_t d, int64_t ld, i
                              int exclude_self, int32_t* out_idx, float* out_score, int32_t* out_count,
                              void* workspace, size_t workspace_bytes, void* stream);
 /*
+ * Work of the symmetric sweep of nq rows against themselves (tvbf_cosine_topk_sym_f32,
+ * tvbf_topk_accumulate_sym_f32) on the current device: the number of 128 x 128 score tiles
+ * its launches compute, 0 when the shape is not taken.  A plain sweep computes
+ * ceil(nq / 128) * ceil(n / 128) of them; the ratio is the share of the ordered pairs that is
+ * really computed.  Measurement aid, no counterpart in the reference.
+ */
+int64_t tvbf_topk_sym_tiles(int64_t nq);
+/*
  * Diagnostics of the last tvbf_cosine_topk_sym_f32 call on `workspace` (synchronises the stream;
  * no counterpart in the reference): out4 = { shows whose column buffer overflowed (their lists
  * came from the plain re-run), column-side candidates appended in total, the largest number

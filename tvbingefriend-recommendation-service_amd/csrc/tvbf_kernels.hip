@@ -2795,6 +2795,15 @@ size_t tvbf_cosine_topk_sym_workspace_bytes(int64_t n, int64_t d, int k) {
     return sp.ok ? sp.bytes : 0;
 }
 
+int64_t tvbf_topk_sym_tiles(int64_t nq) {
+    if (nq < 1) return 0;
+    SymSweeps sw;
+    if (!plan_sym_sweeps(&sw, nq, device_cus(), 64)) return 0;
+    int64_t tiles = 0;
+    for (int i = 0; i < sw.n; ++i) tiles += sw.work[i].total_tiles;
+    return tiles;
+}
+
 int tvbf_cosine_topk_sym_f32(const float* Z, int64_t n, int64_t d, int64_t ld, int k, float min_similarity,
                              int exclude_self, int32_t* out_idx, float* out_score, int32_t* out_count,
                              void* workspace, size_t workspace_bytes, void* stream) {

@@ -212,6 +212,16 @@ def symmetric_workspace_bytes(n: int, ld: int, k: int) -> int:
     return int(native.load().tvbf_cosine_topk_sym_workspace_bytes(int(n), int(ld), int(k)))
 
 
+def symmetric_tiles(n: int, device=None) -> int:
+    """128 x 128 score tiles the symmetric sweep of n rows against themselves computes on
+    ``device`` (0: shape not taken); a plain sweep computes ceil(n / 128) ** 2."""
+    lib = native.load()
+    if device is not None:
+        with torch.cuda.device(device):
+            return int(lib.tvbf_topk_sym_tiles(int(n)))
+    return int(lib.tvbf_topk_sym_tiles(int(n)))
+
+
 def cosine_topk_symmetric(z: torch.Tensor, k: int, min_similarity: float, *, n: int | None = None,
                           exclude_self: bool = True, workspace: torch.Tensor | None = None,
                           out: TopK | None = None) -> TopK:
@@ -476,6 +486,7 @@ class TopkSession:
         if self.ws_bytes < need:
             raise ValueError(f"workspace holds {self.ws_bytes} bytes, {need} needed for {self.slots} slots")
         self.used = 0
+        self.tiles = 0  # 128 x 128 score tiles the launches so far compute (gated re-runs not counted)
         with torch.cuda.device(self.dev):
             rc = self.lib.tvbf_topk_begin(self.nq, k, self.min_similarity, workspace.data_ptr(), self.ws_bytes,
                                           _stream_ptr())
@@ -515,6 +526,7 @@ class TopkSession:
                 self.z_q.data_ptr(), self.nq, self.q_row0, self.ld, self.ld, self.k, self.min_similarity,
                 1 if self.exclude_self else 0, self.workspace.data_ptr(), self.ws_bytes, self.used, budget,
                 ctypes.byref(used), ctypes.byref(st), _stream_ptr())
+            self.tiles += int(self.lib.tvbf_topk_sym_tiles(self.nq))
         native.check(rc, "tvbf_topk_accumulate_sym_f32")
         self.used += used.value
         return used.value
@@ -559,6 +571,8 @@ class TopkSession:
         self.used += used.value
         if gate is not None:
             self.gated_used += used.value
+        else:
+            self.tiles += ((self.nq + 127) // 128) * ((na + 127) // 128 + (nb + 127) // 128)
         return used.value
 
     def finish(self, out: TopK | None = None, *, extra: torch.Tensor | None = None, gate=None,

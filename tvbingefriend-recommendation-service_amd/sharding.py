@@ -253,6 +253,11 @@ class SymmetricShardJob:
         return send
 
     @property
+    def tiles(self) -> int:
+        """128 x 128 score tiles this rank's sweeps compute (the gated re-run not counted)."""
+        return self.session.tiles + (self.sub.tiles if self.sub is not None else 0)
+
+    @property
     def flag(self) -> torch.Tensor:
         """Overflow words of this rank's column side (summary + one per show), to be max-reduced."""
         return self.side.flags
