@@ -146,6 +146,23 @@ int tvbf_cosine_topk_f32(const float* Zq, int64_t nq, int64_t q_row0, const floa
                          size_t workspace_bytes, void* stream);
 
 /*
+ * tvbf_cosine_topk_f32 without a workspace argument, for callers that cannot allocate device
+ * memory or size a workspace (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc).  It has no counterpart in the reference.  The bound keys and list slots
+ * live in a static device array of TVBF_STATIC_SCRATCH_BYTES inside the library, which every GPU
+ * the library runs on holds until the process ends; sizes whose workspace
+ * (tvbf_topk_workspace_bytes) would be larger are rejected with TVBF_E_BAD_SHAPE.  The call
+ * allocates nothing and gives the same lists as tvbf_cosine_topk_f32, bit for bit.  All calls on
+ * one GPU share the array: calls that overlap on one GPU (different streams or threads) race.
+ * The first call on a device looks up the array's address on that device (make it before a
+ * graph capture starts).
+ */
+#define TVBF_STATIC_SCRATCH_BYTES (32u << 20)
+int tvbf_cosine_topk_static_f32(const float* Zq, int64_t nq, int64_t q_row0, const float* Zall, int64_t n,
+                                int64_t d, int64_t ld, int k, float min_similarity, int exclude_self,
+                                int32_t* out_idx, float* out_score, int32_t* out_count, void* stream);
+
+/*
  * The whole-catalogue case of tvbf_cosine_topk_f32 (Zq == Zall, nq == n, q_row0 == 0:
  * ml/similarity_computer.py:122-124 followed by :159-166 for every show, or the loop of
  * scripts/populate_database.py:170-218 over all shows) computing every pair of shows ONCE.

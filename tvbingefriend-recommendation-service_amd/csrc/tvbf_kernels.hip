@@ -16,6 +16,7 @@
 // The C ABI is declared in include/tvbf.h.  No torch types, no device allocation.
 
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <vector>
 #include <stdint.h>
 #include <stdarg.h>
@@ -2737,6 +2738,51 @@ int tvbf_cosine_topk_f32(const float* Zq, int64_t nq, int64_t q_row0, const floa
                                   workspace, workspace_bytes, 0, max_merge_slots(k), &used, stream);
     if (rc) return rc;
     return tvbf_topk_finish(nq, k, used, out_idx, out_score, out_count, workspace, workspace_bytes, stream);
+}
+
+// ---- tvbf_cosine_topk_f32 for callers that cannot allocate ----
+// The bound keys and the list slots live in a file-scope device array instead of a caller's
+// workspace.  Every GPU the library runs on holds its own copy of the array (at its own address)
+// until the process ends; all calls on one GPU share it, so calls that overlap on one GPU race.
+// Nothing in it needs to survive a call: tvbf_topk_begin rewrites the bound keys and the sweep
+// clears the list slots it uses before writing them.
+static __device__ __align__(256) unsigned char scratch[TVBF_STATIC_SCRATCH_BYTES];
+
+constexpr int SCRATCH_MAX_DEVICES = 64;
+static void* g_scratch_addr[SCRATCH_MAX_DEVICES];  // device address of `scratch` on device i, once resolved
+static std::mutex g_scratch_mutex;
+
+// The array's name is a host-side stand-in, not a device address: the address on the CURRENT
+// device is asked for once per device and kept.
+static int scratch_on_current_device(void** out) {
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= SCRATCH_MAX_DEVICES) return fail(TVBF_E_HIP, "device index %d outside 0..%d", dev, SCRATCH_MAX_DEVICES - 1);
+    std::lock_guard<std::mutex> hold(g_scratch_mutex);
+    if (!g_scratch_addr[dev]) {
+        void* p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p || ((uintptr_t)p & 15)) return fail(TVBF_E_HIP, "hipGetSymbolAddress gave an unusable address");
+        g_scratch_addr[dev] = p;
+    }
+    *out = g_scratch_addr[dev];
+    return TVBF_OK;
+}
+
+int tvbf_cosine_topk_static_f32(const float* Zq, int64_t nq, int64_t q_row0, const float* Zall, int64_t n, int64_t d,
+                                int64_t ld, int k, float min_similarity, int exclude_self, int32_t* out_idx,
+                                float* out_score, int32_t* out_count, void* stream) {
+    if (nq < 0 || n < 1 || k < 1 || k > TVBF_MAX_K) return fail(TVBF_E_BAD_ARG, "bad nq, n or k");
+    const size_t need = tvbf_topk_workspace_bytes(nq > 0 ? nq : 1, n, d, k);
+    if (need == 0 || need > (size_t)TVBF_STATIC_SCRATCH_BYTES)
+        return fail(TVBF_E_BAD_SHAPE,
+                    "these sizes need %zu bytes of scratch, the static buffer holds %zu: use tvbf_cosine_topk_f32 "
+                    "with a workspace of the caller's", need, (size_t)TVBF_STATIC_SCRATCH_BYTES);
+    void* ws = nullptr;
+    int rc = scratch_on_current_device(&ws);
+    if (rc) return rc;
+    return tvbf_cosine_topk_f32(Zq, nq, q_row0, Zall, n, d, ld, k, min_similarity, exclude_self, out_idx, out_score,
+                                out_count, ws, (size_t)TVBF_STATIC_SCRATCH_BYTES, stream);
 }
 
 // ---- symmetric whole-catalogue sweep ----

@@ -26,6 +26,7 @@ SYMBOLS = (
     "tvbf_assemble_normalize_f32",
     "tvbf_topk_workspace_bytes",
     "tvbf_cosine_topk_f32",
+    "tvbf_cosine_topk_static_f32",
     "tvbf_cosine_topk_sym_workspace_bytes",
     "tvbf_cosine_topk_sym_f32",
     "tvbf_cosine_topk_sym_inspect",
@@ -58,6 +59,7 @@ TVBF_MAX_BLOCKS = 8
 TVBF_MAX_K = 100
 TVBF_MAX_SOURCES = 8
 TVBF_MAX_QUERIES = 64
+TVBF_STATIC_SCRATCH_BYTES = 32 << 20
 SRC_DENSE_F32, SRC_DENSE_F64, SRC_DENSE_I64, SRC_DENSE_U8, SRC_CSR_F32, SRC_CSR_F64 = range(6)
 
 
@@ -143,6 +145,8 @@ def load() -> ctypes.CDLL:
     lib.tvbf_cosine_topk_f32.restype = c.c_int
     lib.tvbf_cosine_topk_f32.argtypes = [vp, i64, i64, vp, i64, i64, i64, c.c_int, f32, c.c_int,
                                          vp, vp, vp, vp, sz, vp]
+    lib.tvbf_cosine_topk_static_f32.restype = c.c_int
+    lib.tvbf_cosine_topk_static_f32.argtypes = [vp, i64, i64, vp, i64, i64, i64, c.c_int, f32, c.c_int, vp, vp, vp, vp]
     lib.tvbf_cosine_topk_sym_workspace_bytes.restype = sz
     lib.tvbf_cosine_topk_sym_workspace_bytes.argtypes = [i64, i64, c.c_int]
     lib.tvbf_cosine_topk_sym_f32.restype = c.c_int
