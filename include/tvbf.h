@@ -322,6 +322,29 @@ int tvbf_component_scores_f32(const float* Zq, int64_t nq, const float* Zall, in
                               const int32_t* idx, int k, float* out_comp, void* stream);
 
 /*
+ * The min_similarity cut of scripts/populate_database.py:204-205 and
+ * services/content_based_service.py:220-221 decided in float64, as the reference decides it.
+ * tvbf_cosine_topk_f32 compares fp32 scores; a pair whose float64 score meets the threshold
+ * exactly (three one-hot metadata matches under the default weights: 0.1 * ((1 + 1 + 1) / 3) == 0.1,
+ * kept by the reference) can come out one ulp below it in fp32.  Run the sweep with
+ * min_similarity - band (band about 2e-6, well above the fp32 error of a score), compute the
+ * per-block cosines with tvbf_component_scores_f32, then call this: every kept pair whose fp32
+ * score is below min_similarity + band is re-decided from
+ *     h = (w[0] * c0 + w[1] * c1) + w[2] * c2,   c_g = mean of the cosines of the blocks of group g
+ * in float64 without fused multiply-adds (scripts/populate_database.py:187-192,
+ * ml/similarity_computer.py:122-124) and stays iff h >= min_similarity.  Lists stay sorted;
+ * idx / score / count / comp are compacted in place (-1 / 0 in freed slots).
+ *
+ *   idx, score, count   device, outputs of tvbf_cosine_topk_f32 (nq x k, nq x k, nq)
+ *   comp                device, nq x k x nb fp32 from tvbf_component_scores_f32 (plain cosines)
+ *   block_group         host, nb entries: 0 = genre, 1 = text, 2 = metadata
+ *   group_weight        host, 3 doubles: the weights of the reference's expression
+ */
+int tvbf_refine_min_similarity_f64(int32_t* idx, float* score, int32_t* count, float* comp, int64_t nq, int k,
+                                   int nb, const int32_t* block_group, const double* group_weight,
+                                   double min_similarity, double band, void* stream);
+
+/*
  * K3 -- weighted hybrid sum of three score matrices (any equal-sized buffers):
  * out[i] = (wa*a[i] + wb*b[i]) + wc*c[i] in float64, each product and sum
  * rounded separately, which is bit-for-bit the NumPy expression of

@@ -142,9 +142,48 @@ def dense_tie_free(name, n, d, seed, ks=(20, 50)):
         save[f"score_k{k}"] = s
         save[f"count_k{k}"] = cnt
         save[f"sorted_scores_k{k}"] = sorted_scores(h, k)
+        save[f"clear_k{k}"] = clear_mask(save[f"sorted_scores_k{k}"], k)
     save["stats_mean_std_min_max_median"] = np.array(
         [sc.get_similarity_statistics(h)[q] for q in ("mean", "std", "min", "max", "median")])
     np.savez_compressed(HERE / f"{name}.npz", **save)
+
+
+GAP_CLEAR = 2e-6  # ranks whose score gaps to both neighbours exceed this are held to index equality
+
+
+def clear_mask(srt, k):
+    """Per rank 1..k: True where the gaps to the previous and to the next rank (rank k+1 included)
+    both exceed GAP_CLEAR in the reference's float64 scores, so that fp32 rounding (about 3e-7)
+    cannot reorder them.  ``srt`` are the k+1 largest scores of every row."""
+    gaps = srt[:, :-1] - srt[:, 1:]  # gap between rank r and r+1, r = 1..k
+    ok = gaps > GAP_CLEAR
+    prev_ok = np.concatenate([np.ones((srt.shape[0], 1), bool), ok[:, :-1]], axis=1)
+    return prev_ok & ok
+
+
+def dense_verified_gaps(name, n, d, k, first_seed, min_gap=1e-5, tries=5000):
+    """A fixture on which "top-K indices exactly" is well defined for EVERY rank: the seed is
+    searched until the smallest gap between consecutive float64 scores over ranks 1..k+1 of all rows
+    exceeds ``min_gap`` (verified here, stored with the fixture)."""
+    sc = SimilarityComputer()
+    for seed in range(first_seed, first_seed + tries):
+        x = dense_gaussian(n, d, seed)
+        xn = x.astype(np.float64)
+        xn /= np.linalg.norm(xn, axis=1, keepdims=True)
+        srt = sorted_scores(xn @ xn.T, k)  # cheap pre-check before the reference is asked
+        if (srt[:, :-1] - srt[:, 1:]).min() <= min_gap * 1.01:
+            continue
+        h = sc.compute_genre_similarity(x.astype(np.float64))
+        srt = sorted_scores(h, k)
+        smallest = float((srt[:, :-1] - srt[:, 1:]).min())
+        if smallest <= min_gap:
+            continue
+        idx, s, cnt = ref_topk(h, k, -1.0)
+        np.savez_compressed(HERE / f"{name}.npz", n=n, d=d, seed=seed, k=k, x_sha256=sha(x), idx=idx, score=s,
+                            count=cnt, sorted_scores=srt, min_rank_gap=smallest)
+        print(f"{name}: seed {seed}, smallest gap over ranks 1..{k + 1}: {smallest:.3e}")
+        return
+    raise RuntimeError("no seed with the required gap found")
 
 
 def hybrid_ties(name, n, seed, k=20, min_similarity=0.1, weights=(0.4, 0.5, 0.1)):
@@ -211,6 +250,7 @@ def main():
     edge_frame()
     dense_tie_free("dense_512x64", 512, 64, seed=41001)
     dense_tie_free("dense_2048x512", 2048, 512, seed=41002)
+    dense_verified_gaps("dense_tiefree_256x64", 256, 64, k=20, first_seed=42000)
     hybrid_ties("hybrid_2048", 2048, seed=41003)
     plumbing_100()
     for p in sorted(HERE.glob("*.npz")):

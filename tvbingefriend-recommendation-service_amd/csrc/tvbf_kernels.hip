@@ -1746,6 +1746,69 @@ __global__ __launch_bounds__(256) void component_scores_kernel(const float* __re
 }
 
 // --------------------------------------------------------------------------
+// The final min_similarity cut in float64.  The sweeps compare fp32 scores, and an fp32 sum of
+// weighted block cosines can land one ulp below a threshold that the reference's float64 sum
+// meets exactly (three one-hot metadata matches: 0.1 * ((1 + 1 + 1) / 3) == 0.1 is kept by
+// `score < min_similarity -> break`, fp32 gives 0.099999994).  The caller therefore runs the
+// sweep with the threshold lowered by `band` and this kernel decides the kept pairs whose fp32
+// score lies below min_similarity + band from the per-block cosines: groups of blocks are averaged,
+// then h = (w0 * c0 + w1 * c1) + w2 * c2 in float64 without fused multiply-adds -- the expression of
+// scripts/populate_database.py:187-192 and ml/similarity_computer.py:122-124 -- and a pair stays
+// iff h >= min_similarity.  Survivors keep their order; idx / score / comp rows are compacted.
+// One thread per row: lists are sorted, so a row whose last score clears the band returns at once.
+// --------------------------------------------------------------------------
+struct RefineDesc {
+    int nb;
+    int group[TVBF_MAX_BLOCKS];
+    double weight[3];
+};
+
+__global__ __launch_bounds__(256) void refine_min_similarity_kernel(int32_t* __restrict__ idx, float* __restrict__ score,
+                                                                    int32_t* __restrict__ count, float* __restrict__ comp,
+                                                                    int64_t nq, int k, RefineDesc rd, double min_similarity,
+                                                                    double band) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= nq) return;
+    int c = count[row];
+    if (c > k) c = k;
+    if (c <= 0 || (double)score[row * k + c - 1] >= min_similarity + band) return;
+    int32_t* ri = idx + row * k;
+    float* rs = score + row * k;
+    float* rc = comp + row * k * rd.nb;
+    int w = 0;
+    for (int s = 0; s < c; ++s) {
+        bool keep = true;
+        if ((double)rs[s] < min_similarity + band) {
+            double g[3] = {0.0, 0.0, 0.0};
+            int members[3] = {0, 0, 0};
+            for (int b = 0; b < rd.nb; ++b) {
+                g[rd.group[b]] += (double)rc[s * rd.nb + b];
+                ++members[rd.group[b]];
+            }
+            for (int u = 0; u < 3; ++u)
+                if (members[u] > 1) g[u] = g[u] / (double)members[u];
+            double h = rd.weight[0] * g[0] + rd.weight[1] * g[1];
+            h = h + rd.weight[2] * g[2];
+            keep = h >= min_similarity;
+        }
+        if (keep) {
+            if (w != s) {
+                ri[w] = ri[s];
+                rs[w] = rs[s];
+                for (int b = 0; b < rd.nb; ++b) rc[w * rd.nb + b] = rc[s * rd.nb + b];
+            }
+            ++w;
+        }
+    }
+    for (int s = w; s < c; ++s) {
+        ri[s] = -1;
+        rs[s] = 0.f;
+        for (int b = 0; b < rd.nb; ++b) rc[s * rd.nb + b] = 0.f;
+    }
+    count[row] = w;
+}
+
+// --------------------------------------------------------------------------
 // Ad-hoc queries: a few query vectors against every row of Z (HBM-bound).
 //
 // query_scores_kernel: Z is read once; the queries sit in LDS; a wavefront takes
@@ -3102,6 +3165,28 @@ int tvbf_component_scores_f32(const float* Zq, int64_t nq, const float* Zall, in
     else
         hipLaunchKernelGGL(component_scores_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, Zq,
                            nq, Zall, n, ld, bd, idx, k, out_comp);
+    HIP_TRY(hipGetLastError());
+    return TVBF_OK;
+}
+
+int tvbf_refine_min_similarity_f64(int32_t* idx, float* score, int32_t* count, float* comp, int64_t nq, int k, int nb,
+                                   const int32_t* block_group, const double* group_weight, double min_similarity,
+                                   double band, void* stream) {
+    if (!idx || !score || !count || !comp || !block_group || !group_weight)
+        return fail(TVBF_E_BAD_ARG, "null pointer argument");
+    if (nq < 0 || k < 1 || nb < 1 || nb > TVBF_MAX_BLOCKS) return fail(TVBF_E_BAD_ARG, "bad nq, k or nb");
+    if (min_similarity != min_similarity || !(band >= 0.0)) return fail(TVBF_E_BAD_ARG, "bad min_similarity or band");
+    RefineDesc rd;
+    rd.nb = nb;
+    for (int b = 0; b < TVBF_MAX_BLOCKS; ++b) rd.group[b] = 0;
+    for (int b = 0; b < nb; ++b) {
+        if (block_group[b] < 0 || block_group[b] > 2) return fail(TVBF_E_BAD_ARG, "block_group entries must be 0, 1 or 2");
+        rd.group[b] = block_group[b];
+    }
+    for (int u = 0; u < 3; ++u) rd.weight[u] = group_weight[u];
+    if (nq == 0) return TVBF_OK;
+    hipLaunchKernelGGL(refine_min_similarity_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       idx, score, count, comp, nq, k, rd, min_similarity, band);
     HIP_TRY(hipGetLastError());
     return TVBF_OK;
 }

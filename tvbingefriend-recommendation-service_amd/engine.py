@@ -309,6 +309,34 @@ def component_scores(z_all: torch.Tensor, offsets, scales, idx: torch.Tensor, *,
     return out
 
 
+# how far below min_similarity the fp32 sweep still collects pairs that refine_min_similarity then
+# decides in float64; the fp32 error of a hybrid score is about 3e-7
+THRESHOLD_BAND = 2e-6
+
+
+def refine_min_similarity(top: TopK, comp: torch.Tensor, groups, group_weights, min_similarity: float,
+                          band: float = THRESHOLD_BAND) -> None:
+    """The reference's ``score < min_similarity`` test in float64 for the pairs of ``top`` whose fp32
+    score lies within ``band`` of the threshold (in place; ``top`` must come from a sweep run with
+    ``min_similarity - band``, ``comp`` (nq, k, nb) are its plain per-block cosines).  ``groups[b]``
+    in {0: genre, 1: text, 2: metadata} and the three ``group_weights`` spell the reference's
+    expression (wg * g + wt * t) + wm * mean(metadata blocks)."""
+    _require_cuda(comp, "comp")
+    nq, k = top.idx.shape
+    nb = len(groups)
+    if comp.shape != (nq, k, nb) or not comp.is_contiguous():
+        raise ValueError("comp must be a contiguous (nq, k, len(groups)) tensor")
+    if len(group_weights) != 3:
+        raise ValueError("three group weights (genre, text, metadata)")
+    g = (ctypes.c_int32 * nb)(*[int(v) for v in groups])
+    w = (ctypes.c_double * 3)(*[float(v) for v in group_weights])
+    with torch.cuda.device(comp.device):
+        rc = native.load().tvbf_refine_min_similarity_f64(top.idx.data_ptr(), top.score.data_ptr(), top.count.data_ptr(),
+                                                          comp.data_ptr(), nq, k, nb, g, w, float(min_similarity),
+                                                          float(band), _stream_ptr())
+    native.check(rc, "tvbf_refine_min_similarity_f64")
+
+
 def gram(z_all: torch.Tensor, *, col0: int = 0, width: int | None = None, q_row0: int = 0,
          nq: int | None = None, n: int | None = None) -> torch.Tensor:
     """Dense (nq, n) fp32 matrix z[q rows, cols] @ z[:, cols].T over the column

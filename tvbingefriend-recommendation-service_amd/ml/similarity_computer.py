@@ -232,9 +232,17 @@ class SimilarityComputer:
         n = int(sources[0][1].shape[0]) - (1 if sources[0][0] == "csr" else 0)
         scales = layout.scales()
         z = engine.assemble_normalize(dev_sources, n, layout.offsets, scales)
-        top = engine.catalogue_topk(z, k, min_similarity)
+        # the sweep compares fp32 scores: it runs a hair below the threshold, and the pairs in that
+        # band are decided in float64 from their per-block cosines exactly as the reference does
+        top = engine.catalogue_topk(z, k, min_similarity - engine.THRESHOLD_BAND)
         cscales = layout.component_scales()
         zc = z if cscales == scales else engine.assemble_normalize(dev_sources, n, layout.offsets, cscales)
         comp = engine.component_scores(zc, layout.offsets, cscales, top.idx)
+        if variant == "populate":  # raw weights (scripts/populate_database.py:190-192)
+            group_weights = [self.genre_weight, self.text_weight, self.metadata_weight]
+        else:  # divided by their sum (ml/similarity_computer.py:112-115)
+            total = self.genre_weight + self.text_weight + self.metadata_weight
+            group_weights = [self.genre_weight / total, self.text_weight / total, self.metadata_weight / total]
+        engine.refine_min_similarity(top, comp, layout.groups, group_weights, min_similarity)
         return TopKResult(top.idx.cpu().numpy(), top.score.cpu().numpy(), top.count.cpu().numpy(),
                           feat.fold_components(comp.cpu().numpy(), layout))

@@ -49,6 +49,7 @@ SYMBOLS = (
     "tvbf_gram_stats_workspace_bytes",
     "tvbf_gram_stats_f32",
     "tvbf_component_scores_f32",
+    "tvbf_refine_min_similarity_f64",
     "tvbf_weighted_sum3_f64",
     "tvbf_stats_workspace_bytes",
     "tvbf_upper_tri_stats_f64",
@@ -176,6 +177,9 @@ def load() -> ctypes.CDLL:
     lib.tvbf_component_scores_f32.restype = c.c_int
     lib.tvbf_component_scores_f32.argtypes = [vp, i64, vp, i64, i64, c.POINTER(i32), c.POINTER(f32), c.c_int,
                                               vp, c.c_int, vp, vp]
+    lib.tvbf_refine_min_similarity_f64.restype = c.c_int
+    lib.tvbf_refine_min_similarity_f64.argtypes = [vp, vp, vp, vp, i64, c.c_int, c.c_int, c.POINTER(i32),
+                                                   c.POINTER(c.c_double), c.c_double, c.c_double, vp]
     lib.tvbf_topk_max_slots.restype = c.c_int
     lib.tvbf_topk_max_slots.argtypes = [c.c_int]
     lib.tvbf_topk_workspace_bytes_for_slots.restype = sz

@@ -184,8 +184,10 @@ class ContentBasedRecommendationService:
         q = z[row:row + 1].clone()
         for b in range(layout.nb):
             q[:, layout.offsets[b]:layout.offsets[b + 1]] *= weights[b]
-        top = engine.query_topk(q, z, max(n, 1), min_similarity, self_index=[row])
+        top = engine.query_topk(q, z, max(n, 1), min_similarity - engine.THRESHOLD_BAND, self_index=[row])
         comp = engine.component_scores(z, layout.offsets, [1.0] * layout.nb, top.idx, q_row0=row)
+        # pairs within a hair of the threshold are decided in float64, as the reference decides them
+        engine.refine_min_similarity(top, comp, layout.groups, weights, min_similarity)
         comp = comp.cpu().numpy()[0]
         return self._records(top.idx.cpu().numpy()[0], top.score.cpu().numpy()[0], int(top.count.cpu().numpy()[0]),
                              [comp[:, 0], comp[:, 1], comp[:, 2]], "show_id")
