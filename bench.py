@@ -342,7 +342,7 @@ def main():
             if timed:
                 ev[0].record()
             engine.cosine_topk_symmetric(z_shard, args.k, min_sim, n=nq, workspace=workspace, out=out)
-            tiles_step[0] = engine.symmetric_tiles(nq, dev)
+            tiles_step[0] = engine.symmetric_tiles(nq, ld, args.k, dev)
         elif symmetric:
             job = sharding.SymmetricShardJob(z_shard, shard, args.k, min_sim, slots=slots, workspace=workspace,
                                              colside=side)

@@ -171,9 +171,15 @@ int tvbf_cosine_topk_static_f32(const float* Zq, int64_t nq, int64_t q_row0, con
  * about half of it is computed (0.50-0.53 of the ordered pairs: blocks of rows near the
  * diagonal are computed in both orders to seed the bounds).
  *
- *   d           multiple of 64;  n at least 16 blocks of 128 rows (more than 1920 shows)
+ *   d           multiple of 64
  *   workspace   >= tvbf_cosine_topk_sym_workspace_bytes(n, d, k) bytes, which returns 0 when
  *               the shape is not taken (call tvbf_cosine_topk_f32 then)
+ * Catalogues of up to 16,384 shows take a second route with the same result: the tiles on and
+ * above the diagonal are computed once and stored, with their transposes, as a dense n x n fp32
+ * matrix in the workspace (4 n^2 bytes), and one pass per row selects its list.  Short sweeps
+ * spend most of their time on lists that have not seen enough columns to reject anything; a
+ * stored matrix of this size is cheaper.  Larger catalogues take the fused sweeps described
+ * below, which need at least 16 blocks of 128 rows.
  * Every show has a buffer of 1024 column-side candidates; should one overflow, the show is
  * flagged and a plain sweep restricted to the 128-row blocks that hold flagged shows recomputes
  * their lists on the device, without host synchronisation (it returns at once when nothing is
@@ -191,6 +197,8 @@ int tvbf_cosine_topk_sym_f32(const float* Z, int64_t n, int64_t d, int64_t ld, i
  * really computed.  Measurement aid, no counterpart in the reference.
  */
 int64_t tvbf_topk_sym_tiles(int64_t nq);
+/* The same count for a tvbf_cosine_topk_sym_f32 call with these sizes (it follows the route that call takes). */
+int64_t tvbf_cosine_topk_sym_tiles(int64_t n, int64_t d, int k);
 /*
  * Diagnostics of the last tvbf_cosine_topk_sym_f32 call on `workspace` (synchronises the stream;
  * no counterpart in the reference): out4 = { shows whose column buffer overflowed (their lists

@@ -19,7 +19,8 @@ def _ref_stats(h):
     return np.array([v.mean(), v.std(), v.min(), v.max(), np.median(v)])
 
 
-@pytest.mark.parametrize("n,d", [(2, 32), (3, 8), (129, 40), (700, 96), (1500, 256)])
+@pytest.mark.parametrize("n,d", [(2, 32), (3, 8), (129, 40), (700, 96), (1500, 256), (2, 64), (130, 64), (2500, 192),
+                                 (3100, 128)])
 def test_gram_stats_match_numpy(pkg, device, n, d):
     import torch
 

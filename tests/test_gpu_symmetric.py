@@ -33,16 +33,26 @@ def _z_hybrid(device, n, seed, d_genre=16, d_text=208):
 def _sym(z, k, ms, expect_overflow=False, **kw):
     """Symmetric sweep on its own workspace; checks whether the lists came from the symmetric
     route itself or from the plain re-run after an overflow."""
+    import os
+
     import torch
 
     from tvbingefriend_recommendation_service_amd import engine
 
     n, ld = z.shape
-    nbytes = engine.symmetric_workspace_bytes(n, ld, k)
-    assert nbytes > 0
-    ws = torch.empty((nbytes + 15) // 16 * 2, dtype=torch.int64, device=z.device)
-    top = engine.cosine_topk_symmetric(z, k, ms, workspace=ws, **kw)
-    info = engine.symmetric_inspect(ws, n, ld, k)
+    before = os.environ.get("TVBF_SYM_ROUTE")
+    os.environ["TVBF_SYM_ROUTE"] = "fused"  # small catalogues would otherwise take the stored-matrix route
+    try:
+        nbytes = engine.symmetric_workspace_bytes(n, ld, k)
+        assert nbytes > 0
+        ws = torch.empty((nbytes + 15) // 16 * 2, dtype=torch.int64, device=z.device)
+        top = engine.cosine_topk_symmetric(z, k, ms, workspace=ws, **kw)
+        info = engine.symmetric_inspect(ws, n, ld, k)
+    finally:
+        if before is None:
+            del os.environ["TVBF_SYM_ROUTE"]
+        else:
+            os.environ["TVBF_SYM_ROUTE"] = before
     if expect_overflow is not None:
         assert (info["overflowed"] > 0) == expect_overflow, info
     assert info["appended"] > 0
@@ -186,7 +196,7 @@ def test_symmetric_with_cliques_of_identical_shows(pkg, device):
         _assert_same(sym, plain, f"cliques k={k}")
 
 
-def test_symmetric_shape_limits(pkg, device):
+def test_symmetric_shape_limits(pkg, device, monkeypatch):
     import torch
 
     from tvbingefriend_recommendation_service_amd import engine
@@ -195,11 +205,52 @@ def test_symmetric_shape_limits(pkg, device):
     assert engine.symmetric_workspace_bytes(100_000, 1024 + 32, 20) == 0  # row length must be a multiple of 64
     assert engine.symmetric_workspace_bytes(100_000, 1024, 50) > 0        # large K: lists in global memory
     assert engine.symmetric_workspace_bytes(100_000, 1024, 100) > 0
+    # small catalogues: the scores are stored as an n x n matrix (rows padded to 32 floats)
+    assert engine.symmetric_workspace_bytes(1900, 64, 5) == 1900 * 1920 * 4
+    assert engine.symmetric_workspace_bytes(16384, 64, 5) == 16384 * 16384 * 4
+    assert 0 < engine.symmetric_workspace_bytes(16385, 64, 5) < 16385 * 16385 * 4  # fused sweeps: lists and column buffers
+    assert engine.symmetric_workspace_bytes(1900, 96, 5) == 0
+    monkeypatch.setenv("TVBF_SYM_ROUTE", "fused")
     assert engine.symmetric_workspace_bytes(1900, 64, 5) == 0             # fewer than 16 blocks of 128 shows
     assert engine.symmetric_workspace_bytes(2048, 64, 5) > 0
     z = torch.zeros((100, 64), device=device)
     with pytest.raises(ValueError):
         engine.cosine_topk_symmetric(z, 5, 0.0)
+
+
+@pytest.mark.parametrize("n,d,k,ms,kind", [(1, 64, 5, -1.0, "dense"), (2, 64, 1, -1.0, "dense"), (100, 64, 20, -1.0, "dense"),
+                                           (129, 128, 100, -1.0, "dense"), (1500, 192, 20, 0.02, "dense"),
+                                           (4000, 256, 20, 0.1, "hybrid"), (2600, 320, 50, 0.05, "hybrid"),
+                                           (5000, 64, 20, -1.0, "clique")])
+def test_stored_matrix_route_equals_plain(pkg, device, n, d, k, ms, kind):
+    """Small catalogues: tiles on and above the diagonal stored once with their transposes, one
+    scan per row.  Same fp32 scores, same total order: lists equal the plain sweep's bit for bit --
+    one-tile and ragged catalogues, n < K, thresholds, exact ties, K = 100, self kept or left out."""
+    import torch
+
+    from tvbingefriend_recommendation_service_amd import engine
+
+    if kind == "hybrid":
+        z, _, _ = _z_hybrid(device, n, seed=n + d, d_genre=32, d_text=d - 64)
+    elif kind == "clique":
+        z = _with_clique(device, n, 900, d, seed=n)
+    else:
+        z = engine.normalize_blocks(torch.from_numpy(dense_gaussian(n, d, seed=n + d)).to(device), [0, d], [1.0])
+    assert z.shape[1] == d and engine.symmetric_workspace_bytes(n, d, k) == n * ((n + 31) // 32 * 32) * 4
+    for exclude_self in (True, False):
+        got = engine.cosine_topk_symmetric(z, k, ms, exclude_self=exclude_self)
+        plain = engine.cosine_topk(z, k, ms, exclude_self=exclude_self)
+        torch.cuda.synchronize()
+        _assert_same(got, plain, f"{kind} {n}x{d} k={k} exclude_self={exclude_self}")
+    assert engine.symmetric_tiles(n, d, k) == ((n + 127) // 128) * ((n + 127) // 128 + 1) // 2
+    # the stored scores themselves: the matrix tvbf_gram_f32 returns, symmetric bit for bit
+    if n >= 100:
+        nbytes = engine.symmetric_workspace_bytes(n, d, k)
+        ws = torch.empty((nbytes + 15) // 16 * 2, dtype=torch.int64, device=device)
+        engine.cosine_topk_symmetric(z, k, ms, workspace=ws)
+        m = ws.view(torch.float32)[: n * ((n + 31) // 32 * 32)].view(n, -1)[:, :n]
+        assert torch.equal(m, engine.gram(z))
+        assert torch.equal(m, m.T)
 
 
 def test_symmetric_benchmark_shape_sample(pkg, device):
@@ -346,7 +397,7 @@ def _with_clique(device, n, members, d, seed):
     return engine.normalize_blocks(torch.from_numpy(np.ascontiguousarray(x)).to(device), [0, d], [1.0])
 
 
-def test_symmetric_large_group_of_identical_shows(pkg, device):
+def test_symmetric_large_group_of_identical_shows(pkg, device, monkeypatch):
     """1500 identical shows: each of them ties with all the others at score 1, so their column
     buffers take hundreds of candidates and their bounds are refreshed from the buffered windows
     (a bound can then be one of the buffered keys itself).  Lists must still equal the plain sweep's."""
@@ -355,6 +406,7 @@ def test_symmetric_large_group_of_identical_shows(pkg, device):
     from tvbingefriend_recommendation_service_amd import engine
 
     n, k = 8000, 20
+    monkeypatch.setenv("TVBF_SYM_ROUTE", "fused")  # the column side is what is tested here
     z = _with_clique(device, n, 1500, 128, seed=41)
     nbytes = engine.symmetric_workspace_bytes(n, z.shape[1], k)
     ws = torch.empty((nbytes + 15) // 16 * 2, dtype=torch.int64, device=device)
@@ -408,7 +460,7 @@ def test_symmetric_sharded_job_large_k(pkg, device):
         _assert_same(got, plain, f"k=50 world={world}")
 
 
-def test_topk_calls_can_be_captured_in_a_graph(pkg, device):
+def test_topk_calls_can_be_captured_in_a_graph(pkg, device, monkeypatch):
     """The library allocates nothing and clears memory with kernels, so a caller can capture a
     whole top-K call in a HIP graph: every replay (with unrelated eager work and synchronisations
     in between) must reproduce the eager lists, for the symmetric and for the plain call."""
@@ -420,14 +472,22 @@ def test_topk_calls_can_be_captured_in_a_graph(pkg, device):
     z = engine.normalize_blocks(torch.from_numpy(dense_gaussian(n, d, seed=8)).to(device), [0, d], [1.0])
     ref = engine.cosine_topk(z, k, -1.0)
     torch.cuda.synchronize()
-    nb = engine.symmetric_workspace_bytes(n, d, k)
+    nb = engine.symmetric_workspace_bytes(n, d, k)  # the stored-matrix route at this size
+    monkeypatch.setenv("TVBF_SYM_ROUTE", "fused")
+    nb = max(nb, engine.symmetric_workspace_bytes(n, d, k))
+    monkeypatch.delenv("TVBF_SYM_ROUTE")
     ws = torch.empty((nb + 15) // 16 * 2, dtype=torch.int64, device=device)  # also large enough for the plain call
     out = engine.TopK(torch.empty((n, k), dtype=torch.int32, device=device), torch.empty((n, k), device=device),
                       torch.empty((n,), dtype=torch.int32, device=device))
-    calls = {"symmetric": lambda: engine.cosine_topk_symmetric(z, k, -1.0, workspace=ws, out=out),
+    calls = {"symmetric, stored matrix": lambda: engine.cosine_topk_symmetric(z, k, -1.0, workspace=ws, out=out),
+             "symmetric, fused": lambda: engine.cosine_topk_symmetric(z, k, -1.0, workspace=ws, out=out),
              "plain": lambda: engine.cosine_topk(z, k, -1.0, workspace=ws, out=out)}
     side = torch.cuda.Stream()
     for name, call in calls.items():
+        if name == "symmetric, fused":  # the route is chosen when the call is made, i.e. at capture
+            monkeypatch.setenv("TVBF_SYM_ROUTE", "fused")
+        else:
+            monkeypatch.delenv("TVBF_SYM_ROUTE", raising=False)
         with torch.cuda.stream(side):
             call()  # first call outside the capture (sets kernel attributes)
         torch.cuda.synchronize()

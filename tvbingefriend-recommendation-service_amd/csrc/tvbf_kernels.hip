@@ -1490,6 +1490,423 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
 #endif
 }
 
+// --------------------------------------------------------------------------
+// Z Z^T over the tiles on and above the diagonal, LDS-DMA tile loop, equal stretches.
+//
+// The matrix is symmetric bit for bit, so only the 128 x 128 tiles (rb, ct) with ct >= rb are
+// computed: T (T + 1) / 2 of T^2.  The tiles of all row blocks form one line (row block 0:
+// ct = 0 .. T-1, row block 1: ct = 1 .. T-1, ...), cut into one equal stretch per workgroup as in
+// cosine_topk_dma_kernel; tile loop, LDS layout and MFMA order are that kernel's, so every score
+// is the same fp32 number.  Two epilogues:
+//   TRI_STORE   writes the tile and (off the diagonal) its transpose into a dense n x n matrix --
+//               the scores of a SMALL catalogue, from which matrix_rows_topk_kernel selects.  With
+//               few columns per list the fused epilogue's cold lists cost more than the products
+//               (every score is a candidate until a list has seen a few thousand columns), while
+//               n^2 floats are cheap to store and scan when n is a few thousand;
+//   TRI_STATS   folds the strict upper triangle into sums, extrema and a radix histogram of the
+//               median's key (the statistics of get_similarity_statistics, never stored).
+// Lane = query row (wave w owns rows 32 w .. 32 w + 31 of the row block), register (j, r) =
+// column 32 j + 8 (r >> 2) + 4 half + (r & 3) of the tile.
+// --------------------------------------------------------------------------
+enum { TRI_STORE = 0, TRI_STATS = 1 };
+
+struct TriArgs {
+    const float* z;
+    int64_t n, ld;
+    int d, tiles, items;
+    int64_t total_tiles;
+    float* out;  // TRI_STORE: n x n scores, row stride ldo (a multiple of 4 floats, 16-byte aligned base)
+    int64_t ldo;
+    double* st_part;            // TRI_STATS: as in TopkArgs
+    unsigned* st_hist;
+    const unsigned* st_prefix;
+    int st_level;
+};
+
+// tiles of the row blocks before row block rb
+__host__ __device__ static inline int64_t tri_prefix(int64_t rb, int64_t T) { return rb * T - rb * (rb - 1) / 2; }
+
+template <int EPI>
+__global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tri_dma_kernel(TriArgs a) {
+    static_assert(BK == 32 && BM == 128 && BN == 128, "the DMA tile loop is written for 128 x 128 x 32 tiles");
+    __shared__ __attribute__((aligned(16))) float tileC0[BN * BK];
+    __shared__ __attribute__((aligned(16))) float tileC1[BN * BK];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned* st_lds = reinterpret_cast<unsigned*>(smem);  // TRI_STATS: [2][ST_BINS], then the reduction scratch
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5;
+    const int lrow = wave * 32 + (lane & 31);
+    const int nkb = a.d / BK;
+    const int c_chunk = (tid & 7) ^ ((tid >> 4) & 7);
+    unsigned foff[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+        foff[t] = (unsigned)((lane & 31) * 128 + (((2 * t + half) ^ (((lane & 31) >> 1) & 7)) << 4));
+    f32x16 acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    double st_sum = 0.0, st_sq = 0.0;
+    float st_min = INFINITY, st_max = -INFINITY;
+    unsigned st_pre0 = 0u, st_pre1 = 0u;
+    if (EPI == TRI_STATS) {
+        for (int i = tid; i < 2 * ST_BINS; i += TOPK_THREADS) st_lds[i] = 0u;
+        if (a.st_level > 0) {
+            st_pre0 = a.st_prefix[0];
+            st_pre1 = a.st_prefix[1];
+        }
+    }
+
+#ifdef TVBF_TRI_STAGGER  // experiment: the second workgroup of a compute unit starts TVBF_TRI_STAGGER x 512 cycles late
+    if ((int)blockIdx.x >= a.items / 2)
+        for (int u = 0; u < TVBF_TRI_STAGGER; ++u) __builtin_amdgcn_s_sleep(8);
+#endif
+    const int64_t T = a.tiles;
+    // This workgroup's stretch.  With an even number of workgroups the line is first cut into
+    // items / 2 equal parts and each part into two halves, for workgroups w and w + items / 2: the
+    // dispatcher places those two on one compute unit (workgroups go round the compute units in
+    // order), so every compute unit gets the same number of tiles to within one -- with a handful
+    // of tiles per workgroup, two neighbours that both drew the longer stretch would otherwise
+    // finish a whole tile late.  The cut only moves work; any cut gives the same result.
+    int64_t x_pos, x_end;
+    if ((a.items & 1) == 0) {
+        const int pairs = a.items / 2, pair = (int)blockIdx.x % pairs, second = (int)blockIdx.x / pairs;
+        const int64_t p0 = (a.total_tiles * (int64_t)pair) / pairs, p1 = (a.total_tiles * ((int64_t)pair + 1)) / pairs;
+        const int64_t mid = p0 + (p1 - p0 + 1) / 2;
+        x_pos = second ? mid : p0;
+        x_end = second ? p1 : mid;
+    } else {
+        x_pos = (a.total_tiles * (int64_t)blockIdx.x) / a.items;
+        x_end = (a.total_tiles * ((int64_t)blockIdx.x + 1)) / a.items;
+    }
+    // row block of the first tile: the largest rb with tri_prefix(rb) <= x_pos
+    int rb = 0;
+    {
+        int lo = 0, hi = (int)T - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (tri_prefix(mid, T) <= x_pos) lo = mid; else hi = mid - 1;
+        }
+        rb = lo;
+    }
+#pragma nounroll
+    while (x_pos < x_end) {  // one segment: a run of column tiles of one row block
+    while (tri_prefix(rb + 1, T) <= x_pos) ++rb;
+    const int tile_begin = rb + (int)(x_pos - tri_prefix(rb, T));
+    const int tile_end = x_pos + (T - tile_begin) > x_end ? tile_begin + (int)(x_end - x_pos) : (int)T;
+    x_pos += tile_end - tile_begin;
+    const int64_t q0 = (int64_t)rb * BM;
+
+    unsigned qoff;
+    {
+        int64_t r = lrow;
+        if (q0 + r > a.n - 1) r = a.n - 1 - q0;
+        qoff = (unsigned)((r * a.ld + half * 4) * 4);
+    }
+    unsigned coff[4];
+    const char* tile_ptr = nullptr;
+    auto set_tile = [&](int ct) {
+        const int64_t trow = (int64_t)ct * BN;
+        const int last = (int)(a.n - 1 - trow < BN ? a.n - 1 - trow : BN);  // rows past the end repeat the last row
+        {
+            const uint64_t p = reinterpret_cast<uint64_t>(a.z + trow * a.ld);
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p);
+            const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+            tile_ptr = reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int r = i * 32 + (tid >> 3);
+            if (r > last) r = last;
+            coff[i] = (unsigned)(((unsigned)r * (unsigned)a.ld + c_chunk * 4) * 4);
+        }
+        asm volatile("" : "+v"(qoff));
+    };
+    auto dma_tile = [&](int kb, float* buffer) {
+        const char* cb = tile_ptr + (size_t)kb * (BK * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned off = coff[i];
+            asm volatile("" : "+v"(off));
+            __builtin_amdgcn_global_load_lds((global_cvoid_t)(cb + off),
+                                             (lds_void_t*)(buffer + i * 1024 + wave * 256), 16, 0, 0);
+        }
+    };
+    const char* qbase = reinterpret_cast<const char*>(a.z + q0 * a.ld);
+    f32x4 qreg[2][4];
+    auto load_q = [&](int kb, f32x4(&q)[4]) {
+        const char* qb = qbase + (size_t)kb * (BK * 4);
+        unsigned off = qoff;
+        asm volatile("" : "+v"(off));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) q[t] = *reinterpret_cast<const f32x4*>(qb + off + t * 32);
+    };
+    auto mfma_block = [&](const float* cur, const f32x4(&q)[4]) __attribute__((always_inline)) {
+        const char* cbytes = reinterpret_cast<const char*>(cur);
+        f32x4 cf[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) cf[j] = *reinterpret_cast<const f32x4*>(cbytes + foff[0] + j * 4096);
+        __builtin_amdgcn_sched_group_barrier(0x100, NJ, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x4 cn[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) cn[j] = cf[j];
+            if (t < 3) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) cn[j] = *reinterpret_cast<const f32x4*>(cbytes + foff[t + 1] + j * 4096);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(cf[j][i], q[t][i], acc[j], 0, 0, 0);
+            if (t < 3) __builtin_amdgcn_sched_group_barrier(0x100, NJ, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NJ, 0);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) cf[j] = cn[j];
+        }
+    };
+
+    set_tile(tile_begin);
+    dma_tile(0, tileC0);
+    load_q(0, qreg[0]);
+    __syncthreads();  // first k-block in place (and, in the first segment, the histograms cleared)
+
+#pragma nounroll
+    for (int ct = tile_begin; ct < tile_end; ++ct) {
+#pragma nounroll
+        for (int kb = 0; kb < nkb; kb += 2) {
+            dma_tile(kb + 1, tileC1);
+            load_q(kb + 1, qreg[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_block(tileC0, qreg[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            const bool last = kb + 2 >= nkb;
+            if (!last || ct + 1 < tile_end) {
+                if (last) set_tile(ct + 1);
+                const int next_kb = last ? 0 : kb + 2;
+                dma_tile(next_kb, tileC0);
+                load_q(next_kb, qreg[0]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_block(tileC1, qreg[1]);
+            if (last) {
+                const int64_t col0 = (int64_t)ct * BN;
+                const int64_t qr = q0 + lrow;  // this lane's row of the matrix
+#ifdef TVBF_DIAG_NO_STORE  // timing-only build: the tile is computed and dropped
+                if (EPI == TRI_STORE) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[j][r]));
+                } else
+#endif
+                if (EPI == TRI_STORE) {
+                    // Addresses are a uniform base (tile origin and the register's column, in scalar
+                    // registers) plus one 32-bit per-lane byte offset per orientation.
+                    char* const obase = reinterpret_cast<char*>(a.out);
+                    const int64_t row_bytes = a.ldo * 4;
+                    unsigned voff_n = (unsigned)(((int64_t)lrow * a.ldo + 4 * half) * 4);  // the tile itself: row lrow
+                    unsigned voff_t = (unsigned)(((int64_t)(4 * half) * a.ldo + lrow) * 4);  // its transpose: column lrow
+                    asm volatile("" : "+v"(voff_n), "+v"(voff_t));
+                    if (qr < a.n) {
+                        char* const nb = obase + (q0 * a.ldo + col0) * 4;
+                        char* const tb = obase + (col0 * a.ldo + q0) * 4;
+                        if (col0 + BN <= a.n) {  // every column of the tile exists
+#pragma unroll
+                            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                                for (int g = 0; g < 4; ++g)  // 16 bytes per lane and group of four columns
+                                    *reinterpret_cast<f32x4*>(nb + (32 * j + 8 * g) * 4 + voff_n) =
+                                        f32x4{acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+                            if (ct != rb) {  // the 32 lanes of a half write 128 contiguous bytes of a row
+#pragma unroll
+                                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                                    for (int r = 0; r < 16; ++r)
+                                        *reinterpret_cast<float*>(tb + (32 * j + 8 * (r >> 2) + (r & 3)) * row_bytes + voff_t) =
+                                            acc[j][r];
+                            }
+                        } else {  // last column tile: columns past the end are left out
+                            int rel_end = (int)(a.n - col0) - 4 * half;
+                            asm volatile("" : "+v"(rel_end));
+#pragma unroll
+                            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) {
+                                    const int rel = 32 * j + 8 * (r >> 2) + (r & 3);
+                                    if (rel < rel_end) {
+                                        *reinterpret_cast<float*>(nb + rel * 4 + voff_n) = acc[j][r];
+                                        if (ct != rb) *reinterpret_cast<float*>(tb + rel * row_bytes + voff_t) = acc[j][r];
+                                    }
+                                }
+                        }
+                    }
+                } else {
+                    // pairs row < column < n; in tiles right of the diagonal every pair counts
+                    const int sh = st_shift(a.st_level), prev = a.st_level == 0 ? 32 : st_shift(a.st_level - 1);
+                    const unsigned mask = (1u << st_bits(a.st_level)) - 1u;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int64_t c = col0 + 32 * j + 8 * (r >> 2) + 4 * half + (r & 3);
+                            const float v = acc[j][r];
+                            if (qr < c && c < a.n) {
+                                const unsigned key = f32_to_ordered(v);
+                                if (a.st_level == 0) {
+                                    st_sum += (double)v;
+                                    st_sq += (double)v * (double)v;
+                                    st_min = fminf(st_min, v);
+                                    st_max = fmaxf(st_max, v);
+                                    atomicAdd(&st_lds[key >> sh], 1u);
+                                } else {
+                                    const unsigned pre = key >> prev;
+                                    if (pre == st_pre0) atomicAdd(&st_lds[(key >> sh) & mask], 1u);
+                                    if (pre == st_pre1 && st_pre1 != st_pre0)
+                                        atomicAdd(&st_lds[ST_BINS + ((key >> sh) & mask)], 1u);
+                                }
+                            }
+                        }
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+        }
+    }
+    }  // segments
+
+    if (EPI == TRI_STATS) {
+        // every workgroup leaves its sums in its own slot (folded later in a fixed order) and adds
+        // its histogram to the global one (integer adds: order does not matter)
+        __syncthreads();
+        for (int i = tid; i < 2 * ST_BINS; i += TOPK_THREADS) {
+            const unsigned v = st_lds[i];
+            if (v) atomicAdd(&a.st_hist[i], v);
+        }
+        if (a.st_level == 0) {
+            double* red = reinterpret_cast<double*>(st_lds + 2 * ST_BINS);  // [4][TOPK_THREADS]
+            red[tid] = st_sum;
+            red[TOPK_THREADS + tid] = st_sq;
+            red[2 * TOPK_THREADS + tid] = (double)st_min;
+            red[3 * TOPK_THREADS + tid] = (double)st_max;
+            __syncthreads();
+            if (tid < 4) {
+                double acc0 = red[tid * TOPK_THREADS];
+                for (int i = 1; i < TOPK_THREADS; ++i) {
+                    const double x = red[tid * TOPK_THREADS + i];
+                    acc0 = tid < 2 ? acc0 + x : tid == 2 ? fmin(acc0, x) : fmax(acc0, x);
+                }
+                a.st_part[(int64_t)blockIdx.x * 4 + tid] = acc0;
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------
+// Top-K of the rows of a stored n x n fp32 score matrix (the one cosine_tri_dma_kernel<TRI_STORE>
+// writes): one wavefront per row scans its n scores, 256 per step, with the append / compact
+// selection of the fused kernel and writes the row's final list -- the show itself left out by
+// index, scores below min_similarity dropped, order (score descending, column ascending).
+// --------------------------------------------------------------------------
+constexpr int MROW_CAP = 128;  // candidate buffer of one row (>= TVBF_MAX_K + 28)
+
+__global__ __launch_bounds__(256) void matrix_rows_topk_kernel(const float* __restrict__ m, int64_t n, int64_t ldm,
+                                                               int k, float min_similarity, int exclude_self,
+                                                               int32_t* __restrict__ out_idx,
+                                                               float* __restrict__ out_score,
+                                                               int32_t* __restrict__ out_count) {
+    __shared__ u64 buf_all[4][MROW_CAP];
+    __shared__ u64 mkey_all[4];
+    __shared__ unsigned cnt_all[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= n) return;  // wave-private state only: no workgroup barrier below
+    u64* buf = buf_all[wave];
+    if (lane == 0) {
+        mkey_all[wave] = sentinel_key(min_similarity);
+        cnt_all[wave] = 0u;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    u64 mkey = sentinel_key(min_similarity);
+    float thr = min_similarity;
+    const float* s = m + row * ldm;
+    const int64_t skip = exclude_self ? row : -1;
+    // 512 scores per step (two 16-byte loads per lane); the loads of the next step are issued before
+    // this step's scores are looked at, so a row's scan is not one memory latency per step
+    auto load4 = [&](int64_t c) {
+        f32x4 v = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        if (c + 3 < n) {
+            v = *reinterpret_cast<const f32x4*>(s + c);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (c + u < n) v[u] = s[c + u];
+        }
+        return v;
+    };
+    f32x4 cur[2] = {load4(4 * lane), load4(256 + 4 * lane)};
+#pragma nounroll
+    for (int64_t c0 = 0; c0 < n; c0 += 512) {
+        f32x4 nxt[2] = {load4(c0 + 512 + 4 * lane), load4(c0 + 768 + 4 * lane)};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t c = c0 + 256 * h + 4 * lane;
+            const f32x4 v4 = cur[h];
+            const float best = fmaxf(fmaxf(v4[0], v4[1]), fmaxf(v4[2], v4[3]));
+            if (!__any(best >= thr)) continue;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float v = v4[u];
+                const u64 key = make_key(v, (int)(c + u));
+                bool cand = c + u < n && c + u != skip && v >= thr && key > mkey;
+#pragma nounroll
+                while (__any(cand)) {
+                    if (cand) {
+                        const unsigned pos = atomicAdd(&cnt_all[wave], 1u);
+                        if (pos < (unsigned)MROW_CAP) {
+                            buf[pos] = key;
+                            cand = false;
+                        }
+                    }
+                    if (__any(cand)) {  // buffer full: keep the k best, raise the threshold, retry the rest
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        compact_row(buf, &cnt_all[wave], &mkey_all[wave], k, MROW_CAP, lane, nullptr);
+                        mkey = mkey_all[wave];
+                        thr = fmaxf(ordered_to_f32((uint32_t)(mkey >> 32)), min_similarity);
+                        cand = cand && v >= thr && key > mkey;
+                    }
+                }
+            }
+        }
+        cur[0] = nxt[0];
+        cur[1] = nxt[1];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    compact_row(buf, &cnt_all[wave], &mkey_all[wave], k, MROW_CAP, lane, nullptr);
+    const int have = (int)cnt_all[wave];
+    for (int i = lane; i < k; i += 64) {
+        const u64 key = i < have ? buf[i] : 0ull;
+        out_idx[row * k + i] = i < have ? (int32_t)(0xFFFFFFFFu - (uint32_t)key) : -1;
+        out_score[row * k + i] = i < have ? ordered_to_f32((uint32_t)(key >> 32)) : 0.f;
+    }
+    if (lane == 0) out_count[row] = have;
+}
+
 __global__ __launch_bounds__(256) void bound_init_kernel(u64* __restrict__ bound, int64_t nq, u64 v) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nq) bound[i] = v;
@@ -2866,16 +3283,43 @@ int tvbf_cosine_topk_static_f32(const float* Zq, int64_t nq, int64_t q_row0, con
 // lists instead.  No host synchronisation anywhere.
 struct SymPlan {
     bool ok;
+    bool matrix;        // small catalogue: scores stored as a dense n x n matrix, rows selected from it
+    int64_t ldm;        // row stride of that matrix (floats)
     int s_sym, s_full;  // list slots of the symmetric sweeps (own-columns + half + reduced column side) and of the plain re-run
     int col_cap;
     size_t topk_bytes;  // bounds and list slots: an ordinary top-K workspace
     size_t off_state, state_bytes, bytes;  // the column-side state behind it
 };
 
+// Catalogues up to this many shows take the matrix route (n^2 floats: 1 GiB at the limit).  Below
+// a few thousand columns per list the fused epilogue spends more time on cold lists than the
+// matrix pipe spends on the products; storing and scanning n^2 floats costs 8 n^2 bytes of
+// traffic instead, which at this size is the smaller price (measured at n = 10,000 x 512: 0.6 ms
+// against 1.25 ms).  TVBF_SYM_ROUTE=fused|matrix overrides (test / tuning aid; matrix up to 65,536).
+constexpr int64_t MATRIX_ROUTE_MAX_N = 16384;
+constexpr int64_t MATRIX_ROUTE_HARD_MAX_N = 65536;
+
+static bool sym_route_matrix(int64_t n, int64_t d) {
+    if (!topk_use_dma(d) || n > MATRIX_ROUTE_HARD_MAX_N) return false;
+    if (const char* e = getenv("TVBF_SYM_ROUTE")) {
+        if (!strcmp(e, "fused")) return false;
+        if (!strcmp(e, "matrix")) return true;
+    }
+    if (getenv("TVBF_SYM_SHARDS") || getenv("TVBF_SYM_RING")) return false;  // shard overrides address the fused sweeps
+    return n <= MATRIX_ROUTE_MAX_N;
+}
+
 static SymPlan make_sym_plan(int64_t n, int64_t d, int k) {
     SymPlan sp;
     memset(&sp, 0, sizeof(sp));
     if (n < 1 || k < 1 || k > TVBF_MAX_K) return sp;
+    if (sym_route_matrix(n, d)) {
+        sp.matrix = true;
+        sp.ldm = (n + 31) / 32 * 32;  // rows start on 128-byte boundaries
+        sp.bytes = (size_t)n * (size_t)sp.ldm * sizeof(float);
+        sp.ok = true;
+        return sp;
+    }
     const int row_blocks = (int)((n + BM - 1) / BM);
     const int shards = sym_shards(row_blocks);
     if (shards < 2 || !colside_queue(k, d, nullptr, nullptr)) return sp;
@@ -2899,9 +3343,38 @@ static SymPlan make_sym_plan(int64_t n, int64_t d, int k) {
     return sp;
 }
 
+// stretches of a triangle sweep: one per resident workgroup, none empty
+static int tri_items(int64_t total_tiles, int cus) {
+    int64_t items = (int64_t)cus * 2;
+    if (const char* e = getenv("TVBF_ITEMS")) {  // tuning aid; any value gives the same result
+        const int64_t vset = atoll(e);
+        if (vset >= 1) items = vset;
+    }
+    if (items > total_tiles) items = total_tiles;
+    return (int)(items < 1 ? 1 : items);
+}
+
+static void fill_tri_args(TriArgs* a, const float* Z, int64_t n, int64_t d, int64_t ld) {
+    memset(a, 0, sizeof(*a));
+    a->z = Z;
+    a->n = n;
+    a->ld = ld;
+    a->d = (int)d;
+    a->tiles = tiles_of(n);
+    a->total_tiles = tri_prefix(a->tiles, a->tiles);
+    a->items = tri_items(a->total_tiles, device_cus());
+}
+
 size_t tvbf_cosine_topk_sym_workspace_bytes(int64_t n, int64_t d, int k) {
     const SymPlan sp = make_sym_plan(n, d, k);
     return sp.ok ? sp.bytes : 0;
+}
+
+int64_t tvbf_cosine_topk_sym_tiles(int64_t n, int64_t d, int k) {
+    const SymPlan sp = make_sym_plan(n, d, k);
+    if (!sp.ok) return 0;
+    if (sp.matrix) return tri_prefix(tiles_of(n), tiles_of(n));
+    return tvbf_topk_sym_tiles(n);
 }
 
 int64_t tvbf_topk_sym_tiles(int64_t nq) {
@@ -2925,6 +3398,20 @@ int tvbf_cosine_topk_sym_f32(const float* Z, int64_t n, int64_t d, int64_t ld, i
     if (!sp.ok)
         return fail(TVBF_E_BAD_SHAPE, "the symmetric sweep needs d %% 64 == 0 and at least 16 blocks of 128 rows");
     if (workspace_bytes < sp.bytes) return fail(TVBF_E_BAD_SHAPE, "workspace must be >= %zu bytes", sp.bytes);
+    if (sp.matrix) {  // small catalogue: every tile on or above the diagonal once into a dense matrix, then one scan per row
+        if (min_similarity < -FLT_MAX) min_similarity = -FLT_MAX;  // -inf marks columns past the end
+        TriArgs t;
+        fill_tri_args(&t, Z, n, d, ld);
+        t.out = reinterpret_cast<float*>(workspace);
+        t.ldo = sp.ldm;
+        hipLaunchKernelGGL(cosine_tri_dma_kernel<TRI_STORE>, dim3((unsigned)t.items), dim3(TOPK_THREADS), 0,
+                           (hipStream_t)stream, t);
+        hipLaunchKernelGGL(matrix_rows_topk_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const float*>(workspace), n, sp.ldm, k, min_similarity, exclude_self,
+                           out_idx, out_score, out_count);
+        HIP_TRY(hipGetLastError());
+        return TVBF_OK;
+    }
     // the pieces of the incremental interface in a row: bounds, own block symmetric (which here is
     // the whole catalogue), the plain sweep behind the overflow gate, the merge
     char* ws = reinterpret_cast<char*>(workspace);
@@ -2954,6 +3441,11 @@ int tvbf_cosine_topk_sym_inspect(const void* workspace, int64_t n, int64_t d, in
     if (!workspace || !out4) return fail(TVBF_E_BAD_ARG, "null pointer argument");
     const SymPlan sp = make_sym_plan(n, d, k);
     if (!sp.ok) return fail(TVBF_E_BAD_SHAPE, "not a shape of the symmetric sweep");
+    if (sp.matrix) {  // no column side on this route
+        out4[0] = out4[1] = out4[2] = 0;
+        out4[3] = -1;
+        return TVBF_OK;
+    }
     std::vector<unsigned> host(cs_buf_off(n) / 4);  // summary, per-show flags, then one counter per show
     HIP_TRY(hipMemcpyAsync(host.data(), reinterpret_cast<const char*>(workspace) + sp.off_state, host.size() * 4,
                            hipMemcpyDeviceToHost, (hipStream_t)stream));
@@ -3090,7 +3582,9 @@ size_t tvbf_gram_stats_workspace_bytes(int64_t n) {
     if (n < 2 || n > INT32_MAX - BN) return 0;
     const int tiles = tiles_of(n);
     const int chunk = gram_stats_chunk(tiles);
-    const size_t wgs = (size_t)tiles * (size_t)((tiles + chunk - 1) / chunk);
+    size_t wgs = (size_t)tiles * (size_t)((tiles + chunk - 1) / chunk);
+    const size_t tri = (size_t)tri_items(tri_prefix(tiles, tiles), device_cus());  // the LDS-DMA sweep's workgroups
+    if (tri > wgs) wgs = tri;
     return (sizeof(GramStatsWs) + wgs * 4 * sizeof(double) + 255) / 256 * 256;
 }
 
@@ -3107,36 +3601,52 @@ int tvbf_gram_stats_f32(const float* Z, int64_t n, int64_t d, int64_t ld, double
     if (workspace_bytes < need) return fail(TVBF_E_BAD_SHAPE, "workspace must be >= %zu bytes", need);
     GramStatsWs* ws = reinterpret_cast<GramStatsWs*>(workspace);
     const int tiles = tiles_of(n);
-    const int chunk = gram_stats_chunk(tiles);
-    const int chunks = (tiles + chunk - 1) / chunk;
-    const int64_t wgs = (int64_t)tiles * chunks;
-    if (wgs > INT32_MAX) return fail(TVBF_E_BAD_ARG, "too many workgroups");
     const unsigned long long count = (unsigned long long)n * (unsigned long long)(n - 1) / 2;
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = (size_t)(BM + BN) * LDT * sizeof(float) + 2 * ST_BINS * sizeof(unsigned);
-    if (lds > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(cosine_tile_kernel<MODE_STATS>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(gram_stats_init_kernel, dim3(1), dim3(256), 0, st, ws, count);
-    TopkArgs a;
-    memset(&a, 0, sizeof(a));
-    a.zq = Z;
-    a.rng[0] = ColRange{Z, n, 0, tiles};
-    a.rng[1] = ColRange{Z, 0, 0, 0};
-    a.nq = n;
-    a.ld = ld;
-    a.d = (int)d;
-    a.row_blocks = tiles;
-    a.col_tiles = tiles;
-    a.splits = chunks;
-    a.st_part = ws->part;
-    a.st_hist = ws->hist;
-    a.st_prefix = ws->prefix;
-    a.st_chunk = chunk;
-    for (int level = 0; level < 3; ++level) {
-        a.st_level = level;
-        hipLaunchKernelGGL(cosine_tile_kernel<MODE_STATS>, dim3((unsigned)wgs), dim3(TOPK_THREADS), lds, st, a);
-        hipLaunchKernelGGL(gram_stats_pick_kernel, dim3(1), dim3(256), 0, st, ws, level);
+    int64_t wgs = 0;
+    if (topk_use_dma(d)) {  // LDS-DMA tile loop, the tiles on and right of the diagonal in equal stretches
+        TriArgs t;
+        fill_tri_args(&t, Z, n, d, ld);
+        t.st_part = ws->part;
+        t.st_hist = ws->hist;
+        t.st_prefix = ws->prefix;
+        wgs = t.items;
+        const size_t lds = 2 * ST_BINS * sizeof(unsigned) + 4 * TOPK_THREADS * sizeof(double);
+        for (int level = 0; level < 3; ++level) {
+            t.st_level = level;
+            hipLaunchKernelGGL(cosine_tri_dma_kernel<TRI_STATS>, dim3((unsigned)t.items), dim3(TOPK_THREADS), lds, st, t);
+            hipLaunchKernelGGL(gram_stats_pick_kernel, dim3(1), dim3(256), 0, st, ws, level);
+        }
+    } else {  // register-staged loop (d a multiple of 32 only): row block x chunks of column tiles
+        const int chunk = gram_stats_chunk(tiles);
+        const int chunks = (tiles + chunk - 1) / chunk;
+        wgs = (int64_t)tiles * chunks;
+        if (wgs > INT32_MAX) return fail(TVBF_E_BAD_ARG, "too many workgroups");
+        const size_t lds = (size_t)(BM + BN) * LDT * sizeof(float) + 2 * ST_BINS * sizeof(unsigned);
+        if (lds > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(cosine_tile_kernel<MODE_STATS>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        TopkArgs a;
+        memset(&a, 0, sizeof(a));
+        a.zq = Z;
+        a.rng[0] = ColRange{Z, n, 0, tiles};
+        a.rng[1] = ColRange{Z, 0, 0, 0};
+        a.nq = n;
+        a.ld = ld;
+        a.d = (int)d;
+        a.row_blocks = tiles;
+        a.col_tiles = tiles;
+        a.splits = chunks;
+        a.st_part = ws->part;
+        a.st_hist = ws->hist;
+        a.st_prefix = ws->prefix;
+        a.st_chunk = chunk;
+        for (int level = 0; level < 3; ++level) {
+            a.st_level = level;
+            hipLaunchKernelGGL(cosine_tile_kernel<MODE_STATS>, dim3((unsigned)wgs), dim3(TOPK_THREADS), lds, st, a);
+            hipLaunchKernelGGL(gram_stats_pick_kernel, dim3(1), dim3(256), 0, st, ws, level);
+        }
     }
     hipLaunchKernelGGL(gram_stats_final_kernel, dim3(1), dim3(256), 0, st, ws, wgs, count, out5);
     HIP_TRY(hipGetLastError());

@@ -212,14 +212,14 @@ def symmetric_workspace_bytes(n: int, ld: int, k: int) -> int:
     return int(native.load().tvbf_cosine_topk_sym_workspace_bytes(int(n), int(ld), int(k)))
 
 
-def symmetric_tiles(n: int, device=None) -> int:
-    """128 x 128 score tiles the symmetric sweep of n rows against themselves computes on
-    ``device`` (0: shape not taken); a plain sweep computes ceil(n / 128) ** 2."""
+def symmetric_tiles(n: int, ld: int, k: int, device=None) -> int:
+    """128 x 128 score tiles that :func:`cosine_topk_symmetric` computes for these sizes on ``device``
+    (0: shape not taken); a plain sweep computes ceil(n / 128) ** 2."""
     lib = native.load()
     if device is not None:
         with torch.cuda.device(device):
-            return int(lib.tvbf_topk_sym_tiles(int(n)))
-    return int(lib.tvbf_topk_sym_tiles(int(n)))
+            return int(lib.tvbf_cosine_topk_sym_tiles(int(n), int(ld), int(k)))
+    return int(lib.tvbf_cosine_topk_sym_tiles(int(n), int(ld), int(k)))
 
 
 def cosine_topk_symmetric(z: torch.Tensor, k: int, min_similarity: float, *, n: int | None = None,
@@ -268,14 +268,15 @@ def symmetric_inspect(workspace: torch.Tensor, n: int, ld: int, k: int) -> dict:
 
 def catalogue_topk(z: torch.Tensor, k: int, min_similarity: float, *, n: int | None = None,
                    exclude_self: bool = True) -> TopK:
-    """Top-k of every show against the whole catalogue: the symmetric sweep when the library takes
-    the shape and the catalogue is large enough to gain from it, the plain sweep otherwise.
-    Both give the same lists bit for bit.  TVBF_SWEEP=plain|symmetric overrides the choice."""
+    """Top-k of every show against the whole catalogue: the symmetric call when the library takes
+    the shape (row length a multiple of 64; it stores the scores of a small catalogue as a matrix
+    and runs the fused symmetric sweeps on a large one), the plain sweep otherwise.  All routes give
+    the same lists bit for bit.  TVBF_SWEEP=plain forces the plain sweep."""
     import os
 
     n = z.shape[0] if n is None else int(n)
     choice = os.environ.get("TVBF_SWEEP", "auto")
-    if choice != "plain" and symmetric_workspace_bytes(n, z.shape[1], k) > 0 and (n >= 8192 or choice == "symmetric"):
+    if choice != "plain" and symmetric_workspace_bytes(n, z.shape[1], k) > 0:
         return cosine_topk_symmetric(z, k, min_similarity, n=n, exclude_self=exclude_self)
     return cosine_topk(z, k, min_similarity, n=n, exclude_self=exclude_self)
 

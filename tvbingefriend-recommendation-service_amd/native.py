@@ -31,6 +31,7 @@ SYMBOLS = (
     "tvbf_cosine_topk_sym_f32",
     "tvbf_cosine_topk_sym_inspect",
     "tvbf_topk_sym_tiles",
+    "tvbf_cosine_topk_sym_tiles",
     "tvbf_topk_max_slots",
     "tvbf_topk_workspace_bytes_for_slots",
     "tvbf_topk_begin",
@@ -152,6 +153,8 @@ def load() -> ctypes.CDLL:
     lib.tvbf_cosine_topk_sym_workspace_bytes.argtypes = [i64, i64, c.c_int]
     lib.tvbf_cosine_topk_sym_f32.restype = c.c_int
     lib.tvbf_cosine_topk_sym_f32.argtypes = [vp, i64, i64, i64, c.c_int, f32, c.c_int, vp, vp, vp, vp, sz, vp]
+    lib.tvbf_cosine_topk_sym_tiles.restype = i64
+    lib.tvbf_cosine_topk_sym_tiles.argtypes = [i64, i64, c.c_int]
     lib.tvbf_topk_sym_tiles.restype = i64
     lib.tvbf_topk_sym_tiles.argtypes = [i64]
     lib.tvbf_cosine_topk_sym_inspect.restype = c.c_int
