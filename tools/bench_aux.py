@@ -87,6 +87,12 @@ def main():
     ms = timed(lambda: engine.component_scores(z, offsets, scales, idx), max(2, args.reps // 4))
     out.append(("component_scores_kernel", ms, n * k * 2 * ld * 4, "both rows of every kept pair (cache hits included)"))
 
+    ms = timed(lambda: engine.gram_stats(z), 2)
+    print(json.dumps({"kernel": "gram_stats (three triangle sweeps + radix select)", "ms": round(ms, 3),
+                      "TFLOP/s": round(3.0 * n * n * ld / (ms * 1e-3) / 1e12, 1),
+                      "note": "3 n^2 D flops counted (2 D per pair above the diagonal, three sweeps)",
+                      "workload": f"n={n} d={d}"}), flush=True)
+
     for name, ms, b, what in out:
         gbs = b / (ms * 1e-3) / 1e9
         print(json.dumps({"kernel": name, "ms": round(ms, 4), "algorithmic_bytes": int(b), "GB/s": round(gbs, 1),

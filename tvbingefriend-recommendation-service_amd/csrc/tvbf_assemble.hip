@@ -88,21 +88,37 @@ __global__ __launch_bounds__(256) void assemble_normalize_kernel(Sources src, Bl
     }
     wave_phase();
 
+    // Normalise.  Reduction order of normalize_blocks_*_kernel: lane l takes columns
+    // 256 m + 4 l + 0..3, ascending, one fmaf each, then the butterfly.  16-byte LDS accesses; a
+    // block only visits the 1 KiB pieces of the row it touches.
     for (int b = 0; b < bd.nb; ++b) {
         const int c0 = bd.off[b], c1 = bd.off[b + 1];
+        const unsigned width = (unsigned)(c1 - c0);
         float ss = 0.f;
-        for (int c = c0 + lane; c < c1; c += 64) {
-            const float v = r[c];
-            ss = fmaf(v, v, ss);
+        for (int base = (c0 / 256) * 256; base < c1; base += 256) {
+            const int c = base + 4 * lane;
+            if (c >= ldz) continue;
+            const float4 v = *reinterpret_cast<const float4*>(r + c);
+            if ((unsigned)(c - c0) < width) ss = fmaf(v.x, v.x, ss);
+            if ((unsigned)(c + 1 - c0) < width) ss = fmaf(v.y, v.y, ss);
+            if ((unsigned)(c + 2 - c0) < width) ss = fmaf(v.z, v.z, ss);
+            if ((unsigned)(c + 3 - c0) < width) ss = fmaf(v.w, v.w, ss);
         }
         ss = wave_sum(ss);
         float nrm = sqrtf(ss);
         if (nrm < 10.f * FLT_EPSILON) nrm = 1.f;  // all-zero block stays zero
         const float f = bd.scale[b] / nrm;
-        for (int c = c0 + lane; c < c1; c += 64) r[c] *= f;
+        for (int base = (c0 / 256) * 256; base < c1; base += 256) {
+            const int c = base + 4 * lane;
+            if (c >= ldz) continue;
+            float4 v = *reinterpret_cast<const float4*>(r + c);
+            if ((unsigned)(c - c0) < width) v.x *= f;
+            if ((unsigned)(c + 1 - c0) < width) v.y *= f;
+            if ((unsigned)(c + 2 - c0) < width) v.z *= f;
+            if ((unsigned)(c + 3 - c0) < width) v.w *= f;
+            *reinterpret_cast<float4*>(r + c) = v;  // a lane rewrites only its own four floats
+        }
     }
-    wave_phase();
-
     float* z = Z + row * ldz;
     for (int64_t c = 4 * lane; c < ldz; c += 256)
         *reinterpret_cast<float4*>(z + c) = *reinterpret_cast<const float4*>(r + c);

@@ -93,6 +93,64 @@ __device__ static inline float wave_sum(float v) {
     return v;
 }
 
+// Reduction order of a block's sum of squares (shared with assemble_normalize_kernel, so that both
+// routes give the same bits): lane l accumulates, for m = 0, 1, ..., the elements of columns
+// 256 m + 4 l + 0..3 that belong to the block, in ascending column order, one fmaf each; the 64
+// partial sums are folded by the butterfly of wave_sum.  A lane's elements are four consecutive
+// floats per 1 KiB of the row: 16-byte loads, 1 KiB per wave and load instruction.
+//
+// Fast kernel: the whole row (at most NCH * 256 floats) sits in registers between the one read and
+// the one write -- X and Z each cross the memory system once.
+template <int NCH>
+__global__ __launch_bounds__(256) void normalize_blocks_rows_kernel(const float* __restrict__ X, int64_t n, int d,
+                                                                    int64_t ldx, BlockDesc bd, float* __restrict__ Z,
+                                                                    int64_t ldz) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float* x = X + row * ldx;
+    f32x4 v[NCH];
+#pragma unroll
+    for (int m = 0; m < NCH; ++m) {
+        const int c = 256 * m + 4 * lane;
+        v[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c + 3 < d) {
+            v[m] = *reinterpret_cast<const f32x4*>(x + c);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (c + u < d) v[m][u] = x[c + u];
+        }
+    }
+    for (int b = 0; b < bd.nb; ++b) {
+        const int c0 = bd.off[b];
+        const unsigned width = (unsigned)(bd.off[b + 1] - c0);
+        float ss = 0.f;
+#pragma unroll
+        for (int m = 0; m < NCH; ++m)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if ((unsigned)(256 * m + 4 * lane + u - c0) < width) ss = fmaf(v[m][u], v[m][u], ss);
+        ss = wave_sum(ss);
+        float nrm = sqrtf(ss);
+        if (nrm < 10.f * FLT_EPSILON) nrm = 1.f;  // all-zero block stays zero
+        const float f = bd.scale[b] / nrm;
+#pragma unroll
+        for (int m = 0; m < NCH; ++m)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if ((unsigned)(256 * m + 4 * lane + u - c0) < width) v[m][u] *= f;
+    }
+    float* z = Z + row * ldz;
+#pragma unroll
+    for (int m = 0; m < NCH; ++m) {
+        const int c = 256 * m + 4 * lane;
+        if (c < ldz) *reinterpret_cast<f32x4*>(z + c) = v[m];  // columns [d, ldz) are zero
+    }
+}
+
+// General kernel (any alignment, any row length): the same element-to-lane assignment with
+// 4-byte accesses; the row is read twice.
 __global__ __launch_bounds__(256) void normalize_blocks_kernel(const float* __restrict__ X, int64_t n,
                                                                int d, int64_t ldx, BlockDesc bd,
                                                                float* __restrict__ Z, int64_t ldz) {
@@ -104,15 +162,25 @@ __global__ __launch_bounds__(256) void normalize_blocks_kernel(const float* __re
     for (int b = 0; b < bd.nb; ++b) {
         const int c0 = bd.off[b], c1 = bd.off[b + 1];
         float ss = 0.f;
-        for (int c = c0 + lane; c < c1; c += 64) {
-            const float v = x[c];
-            ss = fmaf(v, v, ss);
-        }
+        for (int base = (c0 / 256) * 256; base < c1; base += 256)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = base + 4 * lane + u;
+                if (c >= c0 && c < c1) {
+                    const float v = x[c];
+                    ss = fmaf(v, v, ss);
+                }
+            }
         ss = wave_sum(ss);
         float nrm = sqrtf(ss);
         if (nrm < 10.f * FLT_EPSILON) nrm = 1.f;  // all-zero block stays zero
         const float f = bd.scale[b] / nrm;
-        for (int c = c0 + lane; c < c1; c += 64) z[c] = x[c] * f;
+        for (int base = (c0 / 256) * 256; base < c1; base += 256)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = base + 4 * lane + u;
+                if (c >= c0 && c < c1) z[c] = x[c] * f;
+            }
     }
     for (int64_t c = d + lane; c < ldz; c += 64) z[c] = 0.f;
 }
@@ -1750,31 +1818,43 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tri_dma_kernel(TriArgs
                         }
                     }
                 } else {
-                    // pairs row < column < n; in tiles right of the diagonal every pair counts
+                    // pairs row < column < n.  Right of the diagonal and inside the matrix every score
+                    // of the tile counts: no test per score there (uniform branch).
                     const int sh = st_shift(a.st_level), prev = a.st_level == 0 ? 32 : st_shift(a.st_level - 1);
                     const unsigned mask = (1u << st_bits(a.st_level)) - 1u;
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int64_t c = col0 + 32 * j + 8 * (r >> 2) + 4 * half + (r & 3);
-                            const float v = acc[j][r];
-                            if (qr < c && c < a.n) {
-                                const unsigned key = f32_to_ordered(v);
-                                if (a.st_level == 0) {
-                                    st_sum += (double)v;
-                                    st_sq += (double)v * (double)v;
-                                    st_min = fminf(st_min, v);
-                                    st_max = fmaxf(st_max, v);
-                                    atomicAdd(&st_lds[key >> sh], 1u);
-                                } else {
-                                    const unsigned pre = key >> prev;
-                                    if (pre == st_pre0) atomicAdd(&st_lds[(key >> sh) & mask], 1u);
-                                    if (pre == st_pre1 && st_pre1 != st_pre0)
-                                        atomicAdd(&st_lds[ST_BINS + ((key >> sh) & mask)], 1u);
-                                }
-                            }
+                    const bool interior = ct > rb && col0 + BN <= a.n && q0 + BM <= a.n;
+                    // this lane's row relative to the tile's first column (small numbers: 32-bit tests)
+                    int rel_row = (int)(qr - col0) - 4 * half, rel_end = (int)(a.n - col0) - 4 * half;
+                    if (qr >= a.n) rel_row = 1 << 20;  // a repeated row past the end: nothing counts
+                    asm volatile("" : "+v"(rel_row), "+v"(rel_end));
+                    auto fold = [&](float v) {
+                        const unsigned key = f32_to_ordered(v);
+                        if (a.st_level == 0) {
+                            st_sum += (double)v;
+                            st_sq += (double)v * (double)v;
+                            st_min = fminf(st_min, v);
+                            st_max = fmaxf(st_max, v);
+                            atomicAdd(&st_lds[key >> sh], 1u);
+                        } else {
+                            const unsigned pre = key >> prev;
+                            if (pre == st_pre0) atomicAdd(&st_lds[(key >> sh) & mask], 1u);
+                            if (pre == st_pre1 && st_pre1 != st_pre0) atomicAdd(&st_lds[ST_BINS + ((key >> sh) & mask)], 1u);
                         }
+                    };
+                    if (interior) {
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) fold(acc[j][r]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int rel = 32 * j + 8 * (r >> 2) + (r & 3);  // column - col0 - 4 half
+                                if (rel > rel_row && rel < rel_end) fold(acc[j][r]);
+                            }
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
@@ -1951,26 +2031,92 @@ __global__ __launch_bounds__(64 * FIN_ROWS) void topk_finalize_kernel(const u64*
         n_extra = 0;
     }
     const int m = (splits + n_extra) * k;
-    const u64 floor_key = bound ? bound[row] : 0ull;
+    u64 floor_key = bound ? bound[row] : 0ull;
+    {   // A full list's K-th key is the K-th best of some of the row's candidates, hence not above the
+        // final K-th key; the largest of them thins the keys before ranking (with many lists per row,
+        // as after a query, most keys fall below it).
+        u64 kth = 0ull;
+        for (int s0 = lane; s0 < splits + n_extra; s0 += 64) {
+            const u64 key = s0 < splits ? partial[((int64_t)s0 * nq + row) * k + (k - 1)]
+                                        : extra[(int64_t)(s0 - splits) * extra_stride + row * k + (k - 1)];
+            if ((uint32_t)key != 0u && key > kth) kth = key;  // empty slots (sentinels) have a zero low word
+        }
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) {
+            const u64 o = __shfl_xor(kth, sft, 64);
+            kth = o > kth ? o : kth;
+        }
+        if (kth > floor_key) floor_key = kth;
+    }
     // gather the non-empty keys of all partial lists, packed (most slots of late splits are empty
     // because the shared bound rejected their columns); `extra` lists (received from other ranks)
     // have the same format, list e at extra + e * extra_stride
     int packed = 0;
-    for (int i0 = 0; i0 < m; i0 += 64) {
-        const int i = i0 + lane;
-        u64 key = 0ull;
-        if (i < m) {
-            const int s = i / k;
-            key = s < splits ? partial[((int64_t)s * nq + row) * k + (i - s * k)]
-                             : extra[(int64_t)(s - splits) * extra_stride + row * k + (i - s * k)];
+    const float inv_k = 1.0f / (float)k;
+    for (int i0 = 0; i0 < m; i0 += 256) {  // four independent loads per lane in flight
+        u64 key[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 64 * u + lane;
+            key[u] = 0ull;
+            if (i < m) {
+                int s = (int)(((float)i + 0.5f) * inv_k);  // i / k (exact: i < 2^20, k <= 100; corrected below)
+                s -= (s * k > i) ? 1 : 0;
+                s += ((s + 1) * k <= i) ? 1 : 0;
+                key[u] = s < splits ? partial[((int64_t)s * nq + row) * k + (i - s * k)]
+                                    : extra[(int64_t)(s - splits) * extra_stride + row * k + (i - s * k)];
+            }
         }
-        const bool real = (uint32_t)key != 0u && key >= floor_key;
-        const u64 mask = __ballot(real);
-        if (real) b[packed + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = key;
-        packed += __builtin_popcountll(mask);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool real = (uint32_t)key[u] != 0u && key[u] >= floor_key;
+            const u64 mask = __ballot(real);
+            if (real) b[packed + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = key[u];
+            packed += __builtin_popcountll(mask);
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    // Long inputs (a query's hundred short lists, none of them full) are thinned before the
+    // quadratic ranking: the K-th best of the first 128 keys is not above the final K-th key, so
+    // keys below it go; repeated while it still removes something.  Keys are unique (one per column).
+#pragma nounroll
+    while (packed > 128) {
+        const u64 my0 = b[lane], my1 = b[lane + 64];
+        int r0 = 0, r1 = 0;
+#pragma nounroll
+        for (int j = 0; j < 128; j += 8) {
+            u64 o[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) o[u] = b[j + u];  // same address in every lane: LDS broadcast
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                r0 += o[u] > my0 ? 1 : 0;
+                r1 += o[u] > my1 ? 1 : 0;
+            }
+        }
+        u64 kth = r0 == k - 1 ? my0 : r1 == k - 1 ? my1 : 0ull;  // exactly one lane holds it
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) {
+            const u64 o = __shfl_xor(kth, sft, 64);
+            kth = o > kth ? o : kth;
+        }
+        int kept = 0;
+#pragma nounroll
+        for (int i0 = 0; i0 < packed; i0 += 64) {  // in place: a step writes at or before the slots it has read
+            const u64 key = i0 + lane < packed ? b[i0 + lane] : 0ull;
+            const bool keep = key >= kth && key != 0ull;
+            const u64 mask = __ballot(keep);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (keep) b[kept + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = key;
+            kept += __builtin_popcountll(mask);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (kept == packed) break;
+        packed = kept;
+    }
     int valid = 0;
     for (int i = lane; i < packed; i += 64) {
         const u64 me = b[i];
@@ -2316,10 +2462,12 @@ __global__ __launch_bounds__(256) void query_select_kernel(const float* __restri
     const int64_t begin = n * list / lists, end = n * (list + 1) / lists;
     const float* s = scores + (int64_t)q * n;
     const int64_t skip = self.col[q];
+    float v_next = begin + lane < end ? s[begin + lane] : -INFINITY;
 #pragma nounroll
     for (int64_t c0 = begin; c0 < end; c0 += 64) {
         const int64_t c = c0 + lane;
-        const float v = c < end ? s[c] : -INFINITY;
+        const float v = v_next;
+        v_next = c + 64 < end ? s[c + 64] : -INFINITY;  // the next step's load is in flight during this step
         const u64 key = make_key(v, (int)c);
         bool cand = c < end && c != skip && v >= thr && key > mkey;
 #pragma nounroll
@@ -2772,8 +2920,20 @@ int tvbf_normalize_blocks_f32(const float* X, int64_t n, int64_t d, int64_t ldx,
     if (n == 0) return TVBF_OK;
     const int64_t grid = (n + 3) / 4;
     if (grid > INT32_MAX) return fail(TVBF_E_BAD_ARG, "n too large");
-    hipLaunchKernelGGL(normalize_blocks_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, X, n,
-                       (int)d, ldx, bd, Z, ldz);
+    // rows in registers when 16-byte accesses are possible and a row fits (<= 4096 floats)
+    const bool vec = (ldx & 3) == 0 && (ldz & 3) == 0 && (((uintptr_t)X | (uintptr_t)Z) & 15) == 0;
+    if (vec && ldz <= 1024)
+        hipLaunchKernelGGL(normalize_blocks_rows_kernel<4>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, X, n,
+                           (int)d, ldx, bd, Z, ldz);
+    else if (vec && ldz <= 2048)
+        hipLaunchKernelGGL(normalize_blocks_rows_kernel<8>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, X, n,
+                           (int)d, ldx, bd, Z, ldz);
+    else if (vec && ldz <= 4096)
+        hipLaunchKernelGGL(normalize_blocks_rows_kernel<16>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, X, n,
+                           (int)d, ldx, bd, Z, ldz);
+    else
+        hipLaunchKernelGGL(normalize_blocks_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, X, n,
+                           (int)d, ldx, bd, Z, ldz);
     HIP_TRY(hipGetLastError());
     return TVBF_OK;
 }
@@ -3465,9 +3625,10 @@ int tvbf_cosine_topk_sym_inspect(const void* workspace, int64_t n, int64_t d, in
     return TVBF_OK;
 }
 
-// Partial lists per query: every selection wave should see a few thousand scores.
+// Partial lists per query: a selection wave scans about a thousand scores (many waves, short scans:
+// a query's latency is what matters), as many lists as one merge takes at most.
 static int query_lists(int64_t n, int k) {
-    int64_t lists = (n + 4095) / 4096;
+    int64_t lists = (n + 1023) / 1024;
     const int cap = max_merge_slots(k);
     if (lists > cap) lists = cap;
     if (lists < 1) lists = 1;
