@@ -311,6 +311,13 @@ def main():
                       flush=True)
         elif symmetric:
             slots, workspace = 96, sym_workspace
+    # a rank's own block (its rows against their own columns) goes through the stored-matrix route
+    # when it is small enough for it: the buffer is allocated once
+    own_matrix = None
+    if world > 1 and args.sweep != "plain":
+        mbytes = engine.own_matrix_bytes(nq, ld)
+        if mbytes:
+            own_matrix = torch.empty((mbytes + 7) // 8, dtype=torch.int64, device=dev)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     kernel_ms = []
     tiles_step = [0]  # 128 x 128 score tiles the sweeps of one step compute on this rank
@@ -345,7 +352,7 @@ def main():
             tiles_step[0] = engine.symmetric_tiles(nq, ld, args.k, dev)
         elif symmetric:
             job = sharding.SymmetricShardJob(z_shard, shard, args.k, min_sim, slots=slots, workspace=workspace,
-                                             colside=side)
+                                             colside=side, own_matrix=own_matrix)
             if timed:
                 ev[0].record()
             job.phase_own()  # overlaps the all-gather of Z
@@ -361,7 +368,10 @@ def main():
             session = engine.TopkSession(z_shard, nq, shard.row0, args.k, min_sim, slots=slots, workspace=workspace)
             if timed:
                 ev[0].record()
-            session.accumulate((z_shard, own[1], own[0]))  # own columns: overlaps the all-gather
+            if own_matrix is not None and world > 1:  # own columns: overlaps the all-gather
+                session.accumulate_own_matrix(own_matrix)
+            else:
+                session.accumulate((z_shard, own[1], own[0]))
             if work is not None:
                 work.wait()
                 session.accumulate((z_all[after[0]:], after[1], after[0]), (z_all, before[1], before[0]))

@@ -174,7 +174,7 @@ int tvbf_cosine_topk_static_f32(const float* Zq, int64_t nq, int64_t q_row0, con
  *   d           multiple of 64
  *   workspace   >= tvbf_cosine_topk_sym_workspace_bytes(n, d, k) bytes, which returns 0 when
  *               the shape is not taken (call tvbf_cosine_topk_f32 then)
- * Catalogues of up to 16,384 shows take a second route with the same result: the tiles on and
+ * Catalogues of up to 24,576 shows take a second route with the same result: the tiles on and
  * above the diagonal are computed once and stored, with their transposes, as a dense n x n fp32
  * matrix in the workspace (4 n^2 bytes), and one pass per row selects its list.  Short sweeps
  * spend most of their time on lists that have not seen enough columns to reject anything; a
@@ -288,6 +288,20 @@ int tvbf_topk_accumulate_sym_f32(const float* Zq, int64_t nq, int64_t q_row0, in
                                  float min_similarity, int exclude_self, void* workspace,
                                  size_t workspace_bytes, int slot0, int max_slots, int* slots_used,
                                  const tvbf_colside* colside, void* stream);
+/*
+ * tvbf_topk_accumulate_matrix_f32: the same block (a shard's nq rows against their own columns)
+ * through the stored-matrix route of tvbf_cosine_topk_sym_f32 -- the tiles on and above the
+ * diagonal once, stored with their transposes as an nq x nq fp32 matrix in `matrix`, one scan per
+ * row -- for blocks of up to 65,536 rows (faster than the fused sweeps up to a few ten thousand).
+ * Writes ONE list slot (slot0) and raises the rows' bound keys.  d % 64 == 0;
+ * `matrix`: device, >= tvbf_topk_matrix_bytes(nq, d) bytes (0: shape not taken), 16-byte aligned.
+ * No counterpart in the reference.
+ */
+size_t tvbf_topk_matrix_bytes(int64_t nq, int64_t d);
+int tvbf_topk_accumulate_matrix_f32(const float* Zq, int64_t nq, int64_t q_row0, int64_t d, int64_t ld, int k,
+                                    float min_similarity, int exclude_self, void* workspace,
+                                    size_t workspace_bytes, int slot0, int* slots_used, void* matrix,
+                                    size_t matrix_bytes, void* stream);
 size_t tvbf_topk_colside_bytes(int64_t n_total, int cap);
 int tvbf_topk_colside_begin(void* state, size_t state_bytes, int64_t n_total, int cap, void* stream);
 int tvbf_topk_colside_reset(void* state, size_t state_bytes, int64_t n_total, int cap, void* stream);

@@ -207,8 +207,8 @@ def test_symmetric_shape_limits(pkg, device, monkeypatch):
     assert engine.symmetric_workspace_bytes(100_000, 1024, 100) > 0
     # small catalogues: the scores are stored as an n x n matrix (rows padded to 32 floats)
     assert engine.symmetric_workspace_bytes(1900, 64, 5) == 1900 * 1920 * 4
-    assert engine.symmetric_workspace_bytes(16384, 64, 5) == 16384 * 16384 * 4
-    assert 0 < engine.symmetric_workspace_bytes(16385, 64, 5) < 16385 * 16385 * 4  # fused sweeps: lists and column buffers
+    assert engine.symmetric_workspace_bytes(24576, 64, 5) == 24576 * 24576 * 4
+    assert 0 < engine.symmetric_workspace_bytes(24577, 64, 5) < 24577 * 24577 * 4  # fused sweeps: lists and column buffers
     assert engine.symmetric_workspace_bytes(1900, 96, 5) == 0
     monkeypatch.setenv("TVBF_SYM_ROUTE", "fused")
     assert engine.symmetric_workspace_bytes(1900, 64, 5) == 0             # fewer than 16 blocks of 128 shows
@@ -279,7 +279,7 @@ def test_symmetric_benchmark_shape_sample(pkg, device):
     assert torch.equal(sym.score, plain.score)
 
 
-def _lockstep_ranks(device, z, n, world, k, ms, col_cap=1024, sides=None):
+def _lockstep_ranks(device, z, n, world, k, ms, col_cap=1024, sides=None, own_matrix=False):
     """All ranks of a symmetric sharded job on one GPU, phase by phase, with the collectives
     replaced by indexing; returns the concatenated lists and the reduced overflow flag."""
     import torch
@@ -290,8 +290,12 @@ def _lockstep_ranks(device, z, n, world, k, ms, col_cap=1024, sides=None):
     per = shards[0].per_rank
     z_all = torch.zeros((per * world, z.shape[1]), device=device)
     z_all[:n] = z[:n]
+    def matrix_for(sh):  # a rank's buffer for the scores of its own block
+        nbytes = engine.own_matrix_bytes(sh.rows, z.shape[1]) if own_matrix else 0
+        return torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=device) if nbytes else None
+
     jobs = [sharding.SymmetricShardJob(z_all[r * per : (r + 1) * per], sh, k, ms, col_cap=col_cap,
-                                       colside=None if sides is None else sides[r])
+                                       colside=None if sides is None else sides[r], own_matrix=matrix_for(sh))
             for r, sh in enumerate(shards)]
     for j in jobs:
         j.phase_own()
@@ -322,6 +326,45 @@ def test_symmetric_sharded_job_equals_plain(pkg, device, n, world):
         got, flag = _lockstep_ranks(device, z, n, world, k, ms)
         assert flag == 0
         _assert_same(got, plain, f"n={n} world={world} k={k}")
+
+
+@pytest.mark.parametrize("n,world", [(3000, 2), (5000, 8), (2049, 4), (700, 8), (10, 8), (9100, 4), (13000, 3)])
+def test_symmetric_sharded_job_with_stored_own_blocks(pkg, device, n, world):
+    """Every rank's own block through the stored-matrix route (one list slot and the bound keys),
+    the blocks between shards as before: the lists equal the single-GPU plain sweep bit for bit."""
+    from tvbingefriend_recommendation_service_amd import engine
+
+    z, _, _ = _z_hybrid(device, n, seed=700 + n + world)
+    for k, ms in ((20, 0.1), (50, 0.05)):
+        plain = engine.cosine_topk(z, k, ms)
+        got, _ = _lockstep_ranks(device, z, n, world, k, ms, own_matrix=True)
+        _assert_same(got, plain, f"stored own blocks n={n} world={world} k={k}")
+
+
+def test_plain_sharded_route_with_stored_own_block(pkg, device):
+    """The plain sharded route with the own block through the stored matrix and the other columns
+    as two ranges of the gathered matrix: lists of the single sweep."""
+    import torch
+
+    from tvbingefriend_recommendation_service_amd import engine, sharding
+
+    n, k, ms, world = 7000, 20, 0.1, 3
+    z, _, _ = _z_hybrid(device, n, seed=31)
+    full = engine.cosine_topk(z, k, ms)
+    for rank in range(world):
+        sh = sharding.shard_bounds(n, world, rank)
+        own, after, before = sharding.column_pieces(sh)
+        zq = z[sh.row0:sh.row0 + sh.rows].contiguous()
+        ses = engine.TopkSession(zq, sh.rows, sh.row0, k, ms)
+        nbytes = engine.own_matrix_bytes(sh.rows, z.shape[1])
+        assert nbytes == sh.rows * ((sh.rows + 31) // 32 * 32) * 4
+        assert ses.accumulate_own_matrix(torch.empty(nbytes // 8 + 1, dtype=torch.int64, device=device)) == 1
+        ses.accumulate((z[after[0]:], after[1], after[0]), (z, before[1], before[0]))
+        top = ses.finish()
+        torch.cuda.synchronize()
+        sl = slice(sh.row0, sh.row0 + sh.rows)
+        for f in ("idx", "score", "count"):
+            assert torch.equal(getattr(top, f), getattr(full, f)[sl]), (rank, f)
 
 
 @pytest.mark.parametrize("n,world,shards,ring", [(9000, 2, 4, 2), (9100, 4, 2, 3), (13000, 3, 3, 4)])

@@ -1,6 +1,6 @@
 """Per-rank device time of the symmetric sharded sweep, all ranks run one after the other on ONE
 GPU in lockstep (collectives replaced by indexing, so communication is not in the numbers).
-usage: simulate_sym_ranks.py N D K WORLD"""
+usage: simulate_sym_ranks.py N D K WORLD [matrix]   ("matrix": own blocks through the stored-matrix route)"""
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -9,6 +9,7 @@ import tvbf_amd  # noqa
 from tvbingefriend_recommendation_service_amd import engine, sharding
 
 n, d, k, world = (int(v) for v in sys.argv[1:5])
+use_matrix = len(sys.argv) > 5 and sys.argv[5] == "matrix"
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev); g.manual_seed(30001)
 x = torch.zeros((n, d), device=dev)
@@ -37,7 +38,10 @@ def timed(fn):
     return out, e0.elapsed_time(e1)
 
 for rep in range(2):
-    jobs = [sharding.SymmetricShardJob(z_all[r * per:(r + 1) * per], sh, k, ms) for r, sh in enumerate(shards)]
+    def buf(sh):
+        nb = engine.own_matrix_bytes(sh.rows, z_all.shape[1]) if use_matrix else 0
+        return torch.empty(nb // 8 + 1, dtype=torch.int64, device=dev) if nb else None
+    jobs = [sharding.SymmetricShardJob(z_all[r * per:(r + 1) * per], sh, k, ms, own_matrix=buf(sh)) for r, sh in enumerate(shards)]
     t_own = [timed(j.phase_own)[1] for j in jobs]
     bounds_all = torch.cat([j.own_bounds() for j in jobs])
     t_half = [timed(lambda j=j: j.phase_half(z_all, bounds_all))[1] for j in jobs]

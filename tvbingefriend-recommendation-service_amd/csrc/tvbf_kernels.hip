@@ -1902,11 +1902,16 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tri_dma_kernel(TriArgs
 // --------------------------------------------------------------------------
 constexpr int MROW_CAP = 128;  // candidate buffer of one row (>= TVBF_MAX_K + 28)
 
+// TO_SLOT: the rows are a shard's own block of a larger job (matrix column c is global column
+// col_base + c); the list goes to a partial-list slot and a full list's K-th key raises the row's
+// bound key, as a fused sweep over these columns would have done.
+template <bool TO_SLOT>
 __global__ __launch_bounds__(256) void matrix_rows_topk_kernel(const float* __restrict__ m, int64_t n, int64_t ldm,
                                                                int k, float min_similarity, int exclude_self,
                                                                int32_t* __restrict__ out_idx,
                                                                float* __restrict__ out_score,
-                                                               int32_t* __restrict__ out_count) {
+                                                               int32_t* __restrict__ out_count, int64_t col_base,
+                                                               u64* __restrict__ slot, u64* __restrict__ bound) {
     __shared__ u64 buf_all[4][MROW_CAP];
     __shared__ u64 mkey_all[4];
     __shared__ unsigned cnt_all[4];
@@ -1950,7 +1955,7 @@ __global__ __launch_bounds__(256) void matrix_rows_topk_kernel(const float* __re
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const float v = v4[u];
-                const u64 key = make_key(v, (int)(c + u));
+                const u64 key = make_key(v, (int)(col_base + c + u));
                 bool cand = c + u < n && c + u != skip && v >= thr && key > mkey;
 #pragma nounroll
                 while (__any(cand)) {
@@ -1979,6 +1984,12 @@ __global__ __launch_bounds__(256) void matrix_rows_topk_kernel(const float* __re
     __builtin_amdgcn_wave_barrier();
     compact_row(buf, &cnt_all[wave], &mkey_all[wave], k, MROW_CAP, lane, nullptr);
     const int have = (int)cnt_all[wave];
+    if (TO_SLOT) {
+        for (int i = lane; i < k; i += 64) slot[row * k + i] = i < have ? buf[i] : sentinel_key(min_similarity);
+        if (lane == 0 && have == k)
+            atomicMax(reinterpret_cast<unsigned long long*>(bound + row), (unsigned long long)buf[k - 1]);
+        return;
+    }
     for (int i = lane; i < k; i += 64) {
         const u64 key = i < have ? buf[i] : 0ull;
         out_idx[row * k + i] = i < have ? (int32_t)(0xFFFFFFFFu - (uint32_t)key) : -1;
@@ -3451,12 +3462,14 @@ struct SymPlan {
     size_t off_state, state_bytes, bytes;  // the column-side state behind it
 };
 
-// Catalogues up to this many shows take the matrix route (n^2 floats: 1 GiB at the limit).  Below
+// Catalogues up to this many shows take the matrix route (n^2 floats: 2.4 GB at the limit).  Below
 // a few thousand columns per list the fused epilogue spends more time on cold lists than the
 // matrix pipe spends on the products; storing and scanning n^2 floats costs 8 n^2 bytes of
-// traffic instead, which at this size is the smaller price (measured at n = 10,000 x 512: 0.6 ms
-// against 1.25 ms).  TVBF_SYM_ROUTE=fused|matrix overrides (test / tuning aid; matrix up to 65,536).
-constexpr int64_t MATRIX_ROUTE_MAX_N = 16384;
+// traffic instead, which at these sizes is the smaller price (measured at D = 512: 0.64 against
+// 1.25 ms at n = 10,000, 1.56 against 2.12 ms at 16,384, 3.04 against 3.66 ms at 24,000; the
+// fused sweeps win from about 40,000 shows on, and their workspace grows with n, not n^2).
+// TVBF_SYM_ROUTE=fused|matrix overrides (test / tuning aid; matrix up to 65,536).
+constexpr int64_t MATRIX_ROUTE_MAX_N = 24576;
 constexpr int64_t MATRIX_ROUTE_HARD_MAX_N = 65536;
 
 static bool sym_route_matrix(int64_t n, int64_t d) {
@@ -3566,9 +3579,9 @@ int tvbf_cosine_topk_sym_f32(const float* Z, int64_t n, int64_t d, int64_t ld, i
         t.ldo = sp.ldm;
         hipLaunchKernelGGL(cosine_tri_dma_kernel<TRI_STORE>, dim3((unsigned)t.items), dim3(TOPK_THREADS), 0,
                            (hipStream_t)stream, t);
-        hipLaunchKernelGGL(matrix_rows_topk_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(matrix_rows_topk_kernel<false>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                            reinterpret_cast<const float*>(workspace), n, sp.ldm, k, min_similarity, exclude_self,
-                           out_idx, out_score, out_count);
+                           out_idx, out_score, out_count, (int64_t)0, (u64*)nullptr, (u64*)nullptr);
         HIP_TRY(hipGetLastError());
         return TVBF_OK;
     }
@@ -3595,6 +3608,45 @@ int tvbf_cosine_topk_sym_f32(const float* Z, int64_t n, int64_t d, int64_t ld, i
     if (rc) return rc;
     return tvbf_topk_finish_ex(n, k, used, nullptr, 0, 0, flag + OVF_SHOWS, used, used_full, out_idx, out_score,
                                out_count, workspace, sp.topk_bytes, stream);
+}
+
+// The own block of a shard (its nq rows against the columns that are those same rows) through the
+// stored-matrix route, inside an incremental sequence: one list slot per row and the bound keys.
+size_t tvbf_topk_matrix_bytes(int64_t nq, int64_t d) {
+    if (nq < 1 || nq > MATRIX_ROUTE_HARD_MAX_N || !topk_use_dma(d)) return 0;
+    return (size_t)nq * (size_t)((nq + 31) / 32 * 32) * sizeof(float);
+}
+
+int tvbf_topk_accumulate_matrix_f32(const float* Zq, int64_t nq, int64_t q_row0, int64_t d, int64_t ld, int k,
+                                    float min_similarity, int exclude_self, void* workspace, size_t workspace_bytes,
+                                    int slot0, int* slots_used, void* matrix, size_t matrix_bytes, void* stream) {
+    if (!slots_used) return fail(TVBF_E_BAD_ARG, "slots_used must be non-null");
+    *slots_used = 0;
+    int rc = validate_accumulate(Zq, nq, q_row0, d, ld, Zq, nq, q_row0, nullptr, 0, 0, k, min_similarity, workspace,
+                                 slot0, 1);
+    if (rc) return rc;
+    if (nq == 0) return TVBF_OK;
+    const size_t need_m = tvbf_topk_matrix_bytes(nq, d);
+    if (!need_m) return fail(TVBF_E_BAD_SHAPE, "the stored-matrix route needs d %% 64 == 0 and at most %lld rows",
+                             (long long)MATRIX_ROUTE_HARD_MAX_N);
+    if (!matrix || ((uintptr_t)matrix & 15) || matrix_bytes < need_m)
+        return fail(TVBF_E_BAD_SHAPE, "matrix buffer must be 16-byte aligned and >= %zu bytes", need_m);
+    const size_t need = ws_bound_bytes(nq) + (size_t)(slot0 + 1) * ws_slot_bytes(nq, k);
+    if (workspace_bytes < need) return fail(TVBF_E_BAD_SHAPE, "workspace must be >= %zu bytes", need);
+    if (min_similarity < -FLT_MAX) min_similarity = -FLT_MAX;
+    char* ws = reinterpret_cast<char*>(workspace);
+    TriArgs t;
+    fill_tri_args(&t, Zq, nq, d, ld);
+    t.out = reinterpret_cast<float*>(matrix);
+    t.ldo = (nq + 31) / 32 * 32;
+    hipLaunchKernelGGL(cosine_tri_dma_kernel<TRI_STORE>, dim3((unsigned)t.items), dim3(TOPK_THREADS), 0, (hipStream_t)stream, t);
+    hipLaunchKernelGGL(matrix_rows_topk_kernel<true>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float*>(matrix), nq, t.ldo, k, min_similarity, exclude_self,
+                       (int32_t*)nullptr, (float*)nullptr, (int32_t*)nullptr, q_row0,
+                       reinterpret_cast<u64*>(ws + ws_bound_bytes(nq)) + (size_t)slot0 * nq * k, reinterpret_cast<u64*>(ws));
+    HIP_TRY(hipGetLastError());
+    *slots_used = 1;
+    return TVBF_OK;
 }
 
 int tvbf_cosine_topk_sym_inspect(const void* workspace, int64_t n, int64_t d, int k, int64_t* out4, void* stream) {

@@ -254,6 +254,18 @@ def cosine_topk_symmetric(z: torch.Tensor, k: int, min_similarity: float, *, n: 
     return out
 
 
+OWN_MATRIX_MAX_ROWS = 32768  # blocks up to this size take the stored-matrix route when a buffer is given
+
+
+def own_matrix_bytes(rows: int, ld: int) -> int:
+    """Bytes of the matrix buffer :meth:`TopkSession.accumulate_own_matrix` needs for a block of
+    ``rows`` rows; 0 when that route does not take the shape (row length not a multiple of 64,
+    more than 32,768 rows: the fused sweeps are the better choice there)."""
+    if rows < 1 or rows > OWN_MATRIX_MAX_ROWS:
+        return 0
+    return int(native.load().tvbf_topk_matrix_bytes(int(rows), int(ld)))
+
+
 def symmetric_inspect(workspace: torch.Tensor, n: int, ld: int, k: int) -> dict:
     """What the column side of the last :func:`cosine_topk_symmetric` call on ``workspace`` did
     (synchronises): overflow flag, candidates appended, the busiest show."""
@@ -558,6 +570,27 @@ class TopkSession:
             self.tiles += int(self.lib.tvbf_topk_sym_tiles(self.nq))
         native.check(rc, "tvbf_topk_accumulate_sym_f32")
         self.used += used.value
+        return used.value
+
+    def accumulate_own_matrix(self, matrix: torch.Tensor) -> int:
+        """The block of these rows against their own columns through the stored-matrix route (every
+        pair once, scores stored as an nq x nq matrix in ``matrix``, one scan per row): one list slot.
+        ``matrix``: int64 or float32 device tensor of at least :func:`own_matrix_bytes` bytes."""
+        if self.nq == 0:
+            return 0
+        _require_cuda(matrix, "matrix", None)
+        if self.slots - self.used < 1 or self.max_lists - self.used < 1:
+            raise ValueError("no partial-list slot left")
+        used = ctypes.c_int(0)
+        with torch.cuda.device(self.dev):
+            rc = self.lib.tvbf_topk_accumulate_matrix_f32(
+                self.z_q.data_ptr(), self.nq, self.q_row0, self.ld, self.ld, self.k, self.min_similarity,
+                1 if self.exclude_self else 0, self.workspace.data_ptr(), self.ws_bytes, self.used, ctypes.byref(used),
+                matrix.data_ptr(), matrix.numel() * matrix.element_size(), _stream_ptr())
+        native.check(rc, "tvbf_topk_accumulate_matrix_f32")
+        self.used += used.value
+        t = (self.nq + 127) // 128
+        self.tiles += t * (t + 1) // 2
         return used.value
 
     def slot_lists(self) -> torch.Tensor:

@@ -37,6 +37,8 @@ SYMBOLS = (
     "tvbf_topk_begin",
     "tvbf_topk_accumulate_f32",
     "tvbf_topk_finish",
+    "tvbf_topk_matrix_bytes",
+    "tvbf_topk_accumulate_matrix_f32",
     "tvbf_topk_colside_bytes",
     "tvbf_topk_colside_begin",
     "tvbf_topk_colside_reset",
@@ -159,6 +161,11 @@ def load() -> ctypes.CDLL:
     lib.tvbf_topk_sym_tiles.argtypes = [i64]
     lib.tvbf_cosine_topk_sym_inspect.restype = c.c_int
     lib.tvbf_cosine_topk_sym_inspect.argtypes = [vp, i64, i64, c.c_int, c.POINTER(i64), vp]
+    lib.tvbf_topk_matrix_bytes.restype = sz
+    lib.tvbf_topk_matrix_bytes.argtypes = [i64, i64]
+    lib.tvbf_topk_accumulate_matrix_f32.restype = c.c_int
+    lib.tvbf_topk_accumulate_matrix_f32.argtypes = [vp, i64, i64, i64, i64, c.c_int, f32, c.c_int, vp, sz, c.c_int,
+                                                    c.POINTER(c.c_int), vp, sz, vp]
     lib.tvbf_topk_colside_bytes.restype = sz
     lib.tvbf_topk_colside_bytes.argtypes = [i64, c.c_int]
     lib.tvbf_topk_colside_begin.restype = c.c_int

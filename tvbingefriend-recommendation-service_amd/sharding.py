@@ -186,7 +186,7 @@ class SymmetricShardJob:
     """
 
     def __init__(self, z_shard: torch.Tensor, shard: Shard, k: int, min_similarity: float, *, col_cap: int = 1024,
-                 slots: int = 96, workspace: torch.Tensor | None = None, colside=None):
+                 slots: int = 96, workspace: torch.Tensor | None = None, colside=None, own_matrix=None):
         from . import engine
 
         self.engine, self.shard, self.k, self.min_similarity = engine, shard, int(k), float(min_similarity)
@@ -197,6 +197,9 @@ class SymmetricShardJob:
         self.side = colside if colside is not None else engine.ColumnSide(shard.padded_total, self.dev, cap=col_cap)
         if colside is not None:
             self.side.begin()
+        # scores of the own block as a stored matrix (engine.own_matrix_bytes() bytes): a caller that
+        # keeps such a buffer passes it in; None = the fused sweeps
+        self.own_matrix = own_matrix
         self.normal_slots = 0
         self.per_sweep = _sweep_slots(shard.world, k)
         if self.per_sweep < 6:
@@ -212,7 +215,10 @@ class SymmetricShardJob:
 
     def phase_own(self):
         own, _, _ = column_pieces(self.shard)
-        if self.shard.rows >= 2048:   # large enough for the symmetric sweep inside the block
+        need = self.engine.own_matrix_bytes(self.shard.rows, self.z_shard.shape[1]) if self.own_matrix is not None else 0
+        if need and self.own_matrix.numel() * self.own_matrix.element_size() >= need:
+            self.session.accumulate_own_matrix(self.own_matrix)  # a block of a few ten thousand rows: stored matrix
+        elif self.shard.rows >= 2048:   # large enough for the symmetric sweep inside the block
             self.session.accumulate_own_symmetric(self.side, max_slots=self.per_sweep)
         else:
             self.session.accumulate((self.z_shard, own[1], own[0]), max_slots=self.per_sweep)
@@ -368,7 +374,14 @@ def sharded_topk_symmetric(x_shard: torch.Tensor, offsets, scales, shard: Shard,
         work = dist.all_gather_into_tensor(z_all, z_shard, group=group, async_op=True)
     else:
         work = dist.all_gather(list(z_all.chunk(shard.world, dim=0)), z_shard, group=group, async_op=True)
-    job = job_fn(z_shard, shard, k, min_similarity)
+    if job_fn is SymmetricShardJob and z_shard.is_cuda:
+        from . import engine
+
+        mbytes = engine.own_matrix_bytes(shard.rows, z_shard.shape[1])
+        own_matrix = torch.empty((mbytes + 7) // 8, dtype=torch.int64, device=z_shard.device) if mbytes else None
+        job = job_fn(z_shard, shard, k, min_similarity, own_matrix=own_matrix)
+    else:
+        job = job_fn(z_shard, shard, k, min_similarity)
     job.phase_own()                                       # runs while the shards travel
     bounds_all = gather_words(job.own_bounds(), shard.world, group)
     if work is not None:
