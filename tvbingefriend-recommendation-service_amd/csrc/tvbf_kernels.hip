@@ -1086,8 +1086,23 @@ __device__ static inline void col_drain(const TopkArgs& a, const unsigned* lrowg
     }
 }
 
+// timing-only builds (results wrong by construction): every workgroup reads the same column tile /
+// the same query rows, so that the operand traffic stays in L2
+#ifdef TVBF_DIAG_SAME_C
+#define TVBF_DIAG_CTILE(x) ((x) * 0)
+#else
+#define TVBF_DIAG_CTILE(x) (x)
+#endif
+#ifdef TVBF_DIAG_SAME_Q
+#define TVBF_DIAG_QTILE(x) ((x) * 0)
+#else
+#define TVBF_DIAG_QTILE(x) (x)
+#endif
+#ifndef TVBF_DMA_WGS
+#define TVBF_DMA_WGS 2  // workgroups per compute unit the fused LDS-DMA kernels are compiled for (experiments: 3)
+#endif
 template <bool LIST_GLOBAL, int SYM = SYM_OFF, bool COLSIDE = (SYM == SYM_HALF)>
-__global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkArgs a) {
+__global__ __launch_bounds__(TOPK_THREADS, TVBF_DMA_WGS) void cosine_topk_dma_kernel(TopkArgs a) {
     static_assert(BK == 32 && BM == 128 && BN == 128, "the DMA tile loop is written for 128 x 128 x 32 tiles");
     if (SYM == SYM_OFF && !COLSIDE && a.gate && __hip_atomic_load(a.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
     __shared__ __attribute__((aligned(16))) float tileC0[BN * BK];
@@ -1219,7 +1234,7 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
                 cb_key = __hip_atomic_load(a.col_bound + cr.col_base + trow + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         {  // kept in scalar registers: the DMA instructions take a scalar base
-            const uint64_t p = reinterpret_cast<uint64_t>(cr.z + trow * a.ld);
+            const uint64_t p = reinterpret_cast<uint64_t>(cr.z + TVBF_DIAG_CTILE(trow) * a.ld);
             const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p);
             const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
             tile_ptr = reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
@@ -1244,7 +1259,7 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_topk_dma_kernel(TopkAr
                                              (lds_void_t*)(buffer + i * 1024 + wave * 256), 16, 0, 0);
         }
     };
-    const char* qbase = reinterpret_cast<const char*>(a.zq + q0 * a.ld);
+    const char* qbase = reinterpret_cast<const char*>(a.zq + TVBF_DIAG_QTILE(q0) * a.ld);
     f32x4 qreg[2][4];
     auto load_q = [&](int kb, f32x4(&q)[4]) {
         const char* qb = qbase + (size_t)kb * (BK * 4);
@@ -2629,6 +2644,10 @@ static bool topk_use_dma(int64_t d) {
 }
 
 static int topk_cap(int k, int64_t d) {
+    if (const char* e = getenv("TVBF_CAP")) {  // tuning aid: entries per row beside (LDS lists: including) the K kept
+        const int v = atoi(e);
+        if (v >= 4 && v <= 64 && (topk_list_global(k) || v >= k + 2)) return v;
+    }
 #if TVBF_BN == 256
     if (k <= 20) return 24;  // keeps two workgroups per CU with the wider column tile
 #endif
