@@ -76,7 +76,7 @@ def test_normalize_matches_oracle(pkg, device):
                                 [np.sqrt(0.4), np.sqrt(0.5), np.sqrt(0.1)])
     torch.cuda.synchronize()
     zz = _to_np(z)
-    assert zz.shape == (333, 96)
+    assert zz.shape == (333, 128)  # 73 columns padded to a multiple of 64
     assert np.all(zz[:, 73:] == 0)
     ref = np.hstack([np.sqrt(w) * so.l2_normalize_rows(b) for b, w in ((g, 0.4), (t, 0.5), (m, 0.1))])
     assert np.abs(zz[:, :73] - ref).max() <= 2e-7
@@ -106,6 +106,31 @@ def test_hybrid_ties_min_similarity_and_components(pkg, device):
             ref = bn[r] @ bn[idx[r, :c]].T
             assert np.abs(comp[r, :c, b] - ref).max(initial=0) <= SCORE_TOL
             assert np.all(comp[r, c:, b] == 0)
+
+
+@pytest.mark.parametrize("n,d,k,ms", [(900, 96, 20, -1.0), (1300, 160, 40, 0.02)])
+def test_rows_of_odd_k_tile_count_take_the_staged_loop(pkg, device, n, d, k, ms):
+    """A caller's own Z whose row length is a multiple of 32 but not of 64 (engine.normalize_blocks
+    pads to 64) runs the register-staged tile loop: fused top-K, dense matrix and statistics
+    against the float64 oracle."""
+    import torch
+
+    from tvbingefriend_recommendation_service_amd import engine
+
+    x = dense_gaussian(n, d, seed=n + d)
+    zo = so.l2_normalize_rows(x.astype(np.float64))
+    z = torch.from_numpy(zo.astype(np.float32)).to(device).contiguous()
+    assert z.shape[1] % 64 == 32 and engine.symmetric_workspace_bytes(n, d, k) == 0
+    top = engine.catalogue_topk(z, k, ms)
+    torch.cuda.synchronize()
+    z64 = z.cpu().numpy().astype(np.float64)
+    h = z64 @ z64.T
+    check_topk_against_scores(h, 0, k, ms, _to_np(top.idx), _to_np(top.score), _to_np(top.count), what=f"staged {n}x{d}")
+    s32 = engine.gram(z).cpu().numpy()
+    assert np.abs(s32 - h).max() <= 1e-6
+    got = engine.gram_stats(z).cpu().numpy()
+    v = s32.astype(np.float64)[np.triu_indices(n, k=1)]
+    assert got[2] == v.min() and got[3] == v.max() and got[4] == np.median(v) and abs(got[0] - v.mean()) <= 1e-12
 
 
 def test_row_shard_matches_full(pkg, device):
