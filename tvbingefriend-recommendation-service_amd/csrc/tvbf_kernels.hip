@@ -1098,6 +1098,9 @@ __device__ static inline void col_drain(const TopkArgs& a, const unsigned* lrowg
 #else
 #define TVBF_DIAG_QTILE(x) (x)
 #endif
+#ifndef TVBF_VMEM_GAP
+#define TVBF_VMEM_GAP 4  // MFMAs between two memory instructions of the LDS-DMA tile loops (4 or 8)
+#endif
 #ifndef TVBF_DMA_WGS
 #define TVBF_DMA_WGS 2  // workgroups per compute unit the fused LDS-DMA kernels are compiled for (experiments: 3)
 #endif
@@ -1268,10 +1271,22 @@ __global__ __launch_bounds__(TOPK_THREADS, TVBF_DMA_WGS) void cosine_topk_dma_ke
 #pragma unroll
         for (int t = 0; t < 4; ++t) q[t] = *reinterpret_cast<const f32x4*>(qb + off + t * 32);
     };
-    // One k-block: the MFMAs of the tile in `cur` with the query fragments `q`; its transfers for the
-    // next k-block were issued by the caller.  Fragment reads run one 8-deep step ahead.
-    auto mfma_block = [&](const float* cur, const f32x4(&q)[4]) __attribute__((always_inline)) {
+    // One k-block: the MFMAs of the tile in `cur` with the query fragments `q`, and -- between them --
+    // the eight memory instructions that fetch k-block `kb_next` (four LDS-DMA transfers of the
+    // column tile into `next_buf`, four 16-byte loads of the query fragments into `q_next`).  They
+    // are placed ONE BY ONE, every TVBF_VMEM_GAP MFMAs: issued as a clump in front of the MFMAs,
+    // the memory instructions of the four waves queue up behind one another in the unit's one
+    // address path, and a wave that waits there issues no MFMA -- 4 % of the pipe in a loop without
+    // any epilogue (tools/mfma_loop_probe.hip: 0.90 -> 0.93 of peak).  Fragment reads run one 8-deep
+    // step ahead.
+    auto mfma_block = [&](const float* cur, const f32x4(&q)[4], int kb_next, float* next_buf,
+                          f32x4(&q_next)[4]) __attribute__((always_inline)) {
+        constexpr int PER_STEP = 16 / TVBF_VMEM_GAP;  // memory instructions per 16-MFMA step
         const char* cbytes = reinterpret_cast<const char*>(cur);
+        const char* cb = tile_ptr + (size_t)kb_next * (BK * 4);
+        const char* qb = qbase + (size_t)kb_next * (BK * 4);
+        unsigned qo = qoff;
+        asm volatile("" : "+v"(qo));
         f32x4 cf[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) cf[j] = *reinterpret_cast<const f32x4*>(cbytes + foff[0] + j * 4096);
@@ -1290,8 +1305,28 @@ __global__ __launch_bounds__(TOPK_THREADS, TVBF_DMA_WGS) void cosine_topk_dma_ke
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(cf[j][i], q[t][i], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < PER_STEP; ++g) {
+                const int v = t * PER_STEP + g;
+                if (v < 4) {
+                    // a copy made opaque: the widening to 64 bits stays next to the use (scalar base +
+                    // 32-bit offset)
+                    unsigned off = coff[v];
+                    asm volatile("" : "+v"(off));
+                    __builtin_amdgcn_global_load_lds((global_cvoid_t)(cb + off),
+                                                     (lds_void_t*)(next_buf + v * 1024 + wave * 256), 16, 0, 0);
+                } else if (v < 8) {
+                    q_next[v - 4] = *reinterpret_cast<const f32x4*>(qb + qo + (v - 4) * 32);
+                }
+            }
+            // pin the order: reads of step t+1 first, then the MFMAs of step t with the memory
+            // instructions between them
             if (t < 3) __builtin_amdgcn_sched_group_barrier(0x100, NJ, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NJ, 0);
+#pragma unroll
+            for (int g = 0; g < PER_STEP; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, TVBF_VMEM_GAP, 0);
+                if (t * PER_STEP + g < 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) cf[j] = cn[j];
         }
@@ -1327,11 +1362,9 @@ __global__ __launch_bounds__(TOPK_THREADS, TVBF_DMA_WGS) void cosine_topk_dma_ke
         DL_MARK(7);
 #pragma nounroll
         for (int kb = 0; kb < nkb; kb += 2) {
-            dma_tile(kb + 1, tileC1);
-            load_q(kb + 1, qreg[1]);
-            __builtin_amdgcn_sched_barrier(0);  // the transfers leave before the MFMAs, not after them
+            __builtin_amdgcn_sched_barrier(0);
             DL_MARK(0);
-            mfma_block(tileC0, qreg[0]);
+            mfma_block(tileC0, qreg[0], kb + 1, tileC1, qreg[1]);
             DL_MARK(1);
             // all 64 MFMAs are issued before the wait for this k-block's transfers (the compiler
             // would otherwise sink half of them below the barrier and wait for memory too early)
@@ -1339,15 +1372,14 @@ __global__ __launch_bounds__(TOPK_THREADS, TVBF_DMA_WGS) void cosine_topk_dma_ke
             __syncthreads();
             DL_MARK(2);
             const bool last = kb + 2 >= nkb;
-            if (!last || ct + 1 < tile_end) {  // one issue site for "next k-block" and "first k-block of the next tile"
-                if (last) set_tile(ct + 1);
-                const int next_kb = last ? 0 : kb + 2;
-                dma_tile(next_kb, tileC0);
-                load_q(next_kb, qreg[0]);
-            }
+            // "next k-block" and "first k-block of the next tile" are one issue site; after the last
+            // k-block of a segment it fetches k-block 0 of the same tile once more (valid memory,
+            // never used: the next segment's first transfers follow it in order, or the kernel ends
+            // behind the barrier that waits for it)
+            if (last && ct + 1 < tile_end) set_tile(ct + 1);
             __builtin_amdgcn_sched_barrier(0);
             DL_MARK(3);
-            mfma_block(tileC1, qreg[1]);
+            mfma_block(tileC1, qreg[1], last ? 0 : kb + 2, tileC0, qreg[0]);
             DL_MARK(4);
             if (last) {
                 if (my_gb) {
@@ -1729,8 +1761,15 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tri_dma_kernel(TriArgs
 #pragma unroll
         for (int t = 0; t < 4; ++t) q[t] = *reinterpret_cast<const f32x4*>(qb + off + t * 32);
     };
-    auto mfma_block = [&](const float* cur, const f32x4(&q)[4]) __attribute__((always_inline)) {
+    // one k-block with the memory instructions of the next one between its MFMAs (see cosine_topk_dma_kernel)
+    auto mfma_block = [&](const float* cur, const f32x4(&q)[4], int kb_next, float* next_buf,
+                          f32x4(&q_next)[4]) __attribute__((always_inline)) {
+        constexpr int PER_STEP = 16 / TVBF_VMEM_GAP;  // memory instructions per 16-MFMA step
         const char* cbytes = reinterpret_cast<const char*>(cur);
+        const char* cb = tile_ptr + (size_t)kb_next * (BK * 4);
+        const char* qb = qbase + (size_t)kb_next * (BK * 4);
+        unsigned qo = qoff;
+        asm volatile("" : "+v"(qo));
         f32x4 cf[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) cf[j] = *reinterpret_cast<const f32x4*>(cbytes + foff[0] + j * 4096);
@@ -1749,8 +1788,28 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tri_dma_kernel(TriArgs
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(cf[j][i], q[t][i], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < PER_STEP; ++g) {
+                const int v = t * PER_STEP + g;
+                if (v < 4) {
+                    // a copy made opaque: the widening to 64 bits stays next to the use (scalar base +
+                    // 32-bit offset)
+                    unsigned off = coff[v];
+                    asm volatile("" : "+v"(off));
+                    __builtin_amdgcn_global_load_lds((global_cvoid_t)(cb + off),
+                                                     (lds_void_t*)(next_buf + v * 1024 + wave * 256), 16, 0, 0);
+                } else if (v < 8) {
+                    q_next[v - 4] = *reinterpret_cast<const f32x4*>(qb + qo + (v - 4) * 32);
+                }
+            }
+            // pin the order: reads of step t+1 first, then the MFMAs of step t with the memory
+            // instructions between them
             if (t < 3) __builtin_amdgcn_sched_group_barrier(0x100, NJ, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NJ, 0);
+#pragma unroll
+            for (int g = 0; g < PER_STEP; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, TVBF_VMEM_GAP, 0);
+                if (t * PER_STEP + g < 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) cf[j] = cn[j];
         }
@@ -1765,21 +1824,14 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tri_dma_kernel(TriArgs
     for (int ct = tile_begin; ct < tile_end; ++ct) {
 #pragma nounroll
         for (int kb = 0; kb < nkb; kb += 2) {
-            dma_tile(kb + 1, tileC1);
-            load_q(kb + 1, qreg[1]);
             __builtin_amdgcn_sched_barrier(0);
-            mfma_block(tileC0, qreg[0]);
+            mfma_block(tileC0, qreg[0], kb + 1, tileC1, qreg[1]);
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
             const bool last = kb + 2 >= nkb;
-            if (!last || ct + 1 < tile_end) {
-                if (last) set_tile(ct + 1);
-                const int next_kb = last ? 0 : kb + 2;
-                dma_tile(next_kb, tileC0);
-                load_q(next_kb, qreg[0]);
-            }
+            if (last && ct + 1 < tile_end) set_tile(ct + 1);  // at a segment's end k-block 0 is fetched once more, unused
             __builtin_amdgcn_sched_barrier(0);
-            mfma_block(tileC1, qreg[1]);
+            mfma_block(tileC1, qreg[1], last ? 0 : kb + 2, tileC0, qreg[0]);
             if (last) {
                 const int64_t col0 = (int64_t)ct * BN;
                 const int64_t qr = q0 + lrow;  // this lane's row of the matrix
