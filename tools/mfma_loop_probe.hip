@@ -17,7 +17,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void* global_cvoid_t;
 
-enum { F_LDS = 1, F_BAR = 2, F_DMA = 4, F_Q = 8, F_SPREAD4 = 16, F_SPREAD8 = 32 };  // SPREAD: one memory instruction every 4 / 8 MFMAs
+enum { F_LDS = 1, F_BAR = 2, F_DMA = 4, F_Q = 8, F_SPREAD4 = 16, F_SPREAD8 = 32, F_WAIT4 = 64, F_BUF = 128 };  // BUF: the DMA as buffer_load ... lds (MUBUF) instead of global_load_lds (FLAT)
+//  // WAIT4: the barrier waits for the four DMA transfers only, not for the query loads issued after them  // SPREAD: one memory instruction every 4 / 8 MFMAs
 constexpr int NJ = 4;
 
 template <int F, int WGS>
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(256, WGS) void probe(const float* __restrict__ z, f
         const char* qb = qbase + (size_t)kb_next * 128;
         unsigned qo = qoff;
         asm volatile("" : "+v"(qo));
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(cb), 0, 0x7fffffff, 0x00020000);
         f32x4 cf[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) cf[j] = frag(cbytes, 0, j);
@@ -152,6 +154,10 @@ __global__ __launch_bounds__(256, WGS) void probe(const float* __restrict__ z, f
                         if (F & F_DMA) {
                             unsigned off = coff[v];
                             asm volatile("" : "+v"(off));
+                            if (F & F_BUF)
+                                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(next_buf + v * 1024 + wave * 256),
+                                                                         16, (int)off, 0, 0, 0);
+                            else
                             __builtin_amdgcn_global_load_lds((global_cvoid_t)(cb + off),
                                                              (lds_void_t*)(next_buf + v * 1024 + wave * 256), 16, 0, 0);
                         }
@@ -182,12 +188,18 @@ __global__ __launch_bounds__(256, WGS) void probe(const float* __restrict__ z, f
             for (int kb = 0; kb < nkb; kb += 2) {
                 mfma_block_spread(tileC0, qreg[0], kb + 1, tileC1, qreg[1]);
                 __builtin_amdgcn_sched_barrier(0);
-                if (F & F_BAR) __syncthreads();
+                if (F & F_WAIT4) {
+                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                } else if (F & F_BAR) __syncthreads();
                 const bool last = kb + 2 >= nkb;
                 if (last) set_tile(ct + 1);
                 mfma_block_spread(tileC1, qreg[1], last ? 0 : kb + 2, tileC0, qreg[0]);
                 __builtin_amdgcn_sched_barrier(0);
-                if (F & F_BAR) __syncthreads();
+                if (F & F_WAIT4) {
+                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                } else if (F & F_BAR) __syncthreads();
             }
         }
     } else
@@ -218,9 +230,11 @@ __global__ __launch_bounds__(256, WGS) void probe(const float* __restrict__ z, f
     out[blockIdx.x * 256 + tid] = s + tileC0[tid] + tileC1[tid];
 }
 
+static int g_tiles = 40;  // column tiles per workgroup: 40 = 4.5 ms per launch; argv[2] sets it (1300 = 145 ms, a sustained load)
+
 template <int F, int WGS>
 static void run(const char* what, const float* z, float* out, int64_t ld, int rows, int wgs_per_cu) {
-    const int tiles = 40, nkb = 32;
+    const int tiles = g_tiles, nkb = 32;
     const int grid = 256 * wgs_per_cu;
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
@@ -249,6 +263,14 @@ int main(int argc, char** argv) {
     hipMalloc(&z, (size_t)rows * ld * 4);
     hipMemset(z, 0, (size_t)rows * ld * 4);
     hipMalloc(&out, 1024 * 256 * 4);
+    if (argc > 2) {  // sustained load: a few variants only
+        g_tiles = atoi(argv[2]);
+        run<0, 2>("registers only", z, out, ld, rows, 2);
+        run<F_LDS | F_BAR, 2>("+ LDS + barrier per k-block", z, out, ld, rows, 2);
+        run<F_LDS | F_BAR | F_DMA | F_Q | F_SPREAD4, 2>("all, one memory instruction per 4 MFMAs", z, out, ld, rows, 2);
+        run<F_LDS | F_BAR | F_DMA | F_Q | F_SPREAD4 | F_BUF, 2>("all, per 4 MFMAs, buffer_load lds", z, out, ld, rows, 2);
+        return 0;
+    }
     for (int w = 1; w <= 2; ++w) {
         run<0, 2>("registers only", z, out, ld, rows, w);
         run<F_LDS, 2>("+ fragment reads from LDS", z, out, ld, rows, w);
@@ -262,6 +284,12 @@ int main(int argc, char** argv) {
         run<F_LDS | F_BAR | F_Q | F_SPREAD8, 2>("LDS + barrier + query loads, one per 8 MFMAs", z, out, ld, rows, w);
         run<F_LDS | F_BAR | F_DMA | F_Q | F_SPREAD8, 2>("all, one memory instruction per 8 MFMAs", z, out, ld, rows, w);
         run<F_LDS | F_BAR | F_DMA | F_Q | F_SPREAD4, 2>("all, one memory instruction per 4 MFMAs", z, out, ld, rows, w);
+        run<F_LDS | F_BAR | F_DMA | F_Q | F_SPREAD4 | F_WAIT4, 2>("all, per 4 MFMAs, barrier waits for DMA only", z, out, ld, rows, w);
+        run<F_LDS | F_BAR | F_DMA | F_Q | F_SPREAD8 | F_WAIT4, 2>("all, per 8 MFMAs, barrier waits for DMA only", z, out, ld, rows, w);
+        run<F_LDS | F_BAR | F_DMA | F_Q | F_SPREAD4 | F_BUF, 2>("all, per 4 MFMAs, buffer_load lds", z, out, ld, rows, w);
+        run<F_LDS | F_BAR | F_DMA | F_Q | F_SPREAD8 | F_BUF, 2>("all, per 8 MFMAs, buffer_load lds", z, out, ld, rows, w);
+        run<F_LDS | F_BAR | F_DMA | F_Q | F_SPREAD4 | F_BUF | F_WAIT4, 2>("all, per 4 MFMAs, buffer_load lds, wait DMA only", z, out, ld, rows, w);
+        run<F_LDS | F_BAR | F_DMA | F_Q | F_SPREAD8 | F_BUF | F_WAIT4, 2>("all, per 8 MFMAs, buffer_load lds, wait DMA only", z, out, ld, rows, w);
     }
     run<F_LDS | F_BAR | F_DMA | F_Q, 3>("all, compiled for 3 wg/CU", z, out, ld, rows, 3);
     run<F_LDS, 3>("LDS only, compiled for 3 wg/CU", z, out, ld, rows, 3);

@@ -57,4 +57,9 @@ print(f"cycles per pair of k-blocks (128 MFMAs = 8192 pipe cycles of this wave):
 for nme, v in zip(names, tot):
     print(f"{nme:7s} {v / pairs:8.1f} per pair  {100 * v / tot.sum():5.1f} %")
 print(f"epilogue per tile and wave: {tot[5] / tiles:.0f} cycles; per-tile top: {tot[7] / tiles:.0f}")
+cand = raw[..., 14].sum()
+pops = (raw[..., 15].astype(np.int64) & 0xFFFFFFFF).sum()
+compact = (raw[..., 15].astype(np.int64) >> 32).sum()
+print(f"row side per tile and wave: {cand / tiles:.2f} scores offered to the lists, {pops / tiles:.2f} trips of the pop loop, "
+      f"{compact / tiles:.3f} compactions; per row and sweep: {cand / n:.0f} offered, {compact / n:.1f} compactions")
 print(f"in the loop: {100 * tot.sum() / raw[..., 10].sum():.1f} % of the waves' lifetime")

@@ -316,6 +316,36 @@ __device__ static inline void compact_row(u64* buf, unsigned* cnt, u64* mkey, in
     int valid = (int)*cnt;
     if (valid > cap) valid = cap;
     valid = __builtin_amdgcn_readfirstlane(valid);
+    if (valid <= 32) {
+        // Short list (the usual K = 20: 32 entries): the two halves of the wave share the work.
+        // Lanes l and l + 32 hold key l; the lower half counts the keys above it among entries
+        // 0 .. 15, the upper half among 16 .. 31, and the two counts are added across the halves.
+        const int l = lane & 31, h = lane >> 5;
+        const bool has = l < valid;
+        const u64 my = has ? buf[l] : 0ull;
+        const u64* part = buf + 16 * h;
+        const int cnt_h = valid - 16 * h < 0 ? 0 : valid - 16 * h > 16 ? 16 : valid - 16 * h;  // uniform per half
+        int r = 0;
+        if (valid == 32) {  // full buffer (every compaction in the tile loops): no per-entry test
+#pragma unroll
+            for (int u = 0; u < 16; ++u) r += part[u] > my ? 1 : 0;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) r += (u < cnt_h && part[u] > my) ? 1 : 0;  // buf holds >= 32 entries (cap >= k + slack)
+        }
+        r += __shfl_xor(r, 32, 64);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (h == 0 && has && r < k) buf[r] = my;
+        if (h == 0 && has && r == k - 1) {
+            *mkey = my;
+            if (gbound) atomicMax(reinterpret_cast<unsigned long long*>(gbound), (unsigned long long)my);
+        }
+        if (lane == 0) *cnt = (unsigned)(valid < k ? valid : k);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        return;
+    }
     const bool has0 = lane < valid, has1 = lane + 64 < valid;
     const u64 my0 = has0 ? buf[lane] : 0ull;
     const u64 my1 = has1 ? buf[lane + 64] : 0ull;
@@ -941,7 +971,7 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
 }
 
 // --------------------------------------------------------------------------
-// Fused top-K, tile loop with LDS-DMA (gfx950 global_load_lds_dwordx4).
+// Fused top-K, tile loop with LDS-DMA (gfx950: 16 bytes per lane, buffer_load_dwordx4 ... lds).
 //
 // Same arithmetic and selection as cosine_tile_kernel<MODE_TOPK / MODE_TOPK_G> -- every
 // score is the same fixed-order fp32 chain, so the lists are bit-identical -- but the
@@ -959,6 +989,30 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void* global_cvoid_t;
 constexpr int DMA_SLOTS = 8;  // scores a lane can queue per collect pass
+
+// One LDS-DMA transfer, 16 bytes per lane: global memory at `base + voff` (base uniform) to the
+// LDS at `lds_dst` (uniform) + 16 * lane.  Issued as buffer_load_dwordx4 ... lds, NOT as
+// global_load_lds_dwordx4: the latter is FLAT-encoded, and the compiler's wait-count pass books a
+// FLAT instruction that writes LDS as an access that may complete on either counter -- from then
+// on every wait it inserts is a full one (vmcnt(0) in front of the first fragment read of the next
+// k-block, which waits for the query loads issued last; lgkmcnt(0) instead of the staged counts
+// between the MFMAs).  With the buffer form the waits are counted exactly; in a loop of nothing
+// but the tile loop's MFMAs, fragment reads, transfers and query loads that is 0.93 -> 0.98 of the
+// MFMA peak (tools/mfma_loop_probe.hip).
+#ifndef TVBF_DMA_GLOBAL
+#define TVBF_DMA_GLOBAL 0
+#endif
+__device__ static inline __amdgpu_buffer_rsrc_t dma_window(const char* base) {
+    // raw buffer (stride 0) of 2 GiB from `base`, 32-bit data format
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ static inline void dma16(__amdgpu_buffer_rsrc_t window, const char* base, unsigned voff, float* lds_dst) {
+#if TVBF_DMA_GLOBAL
+    __builtin_amdgcn_global_load_lds((global_cvoid_t)(base + voff), (lds_void_t*)lds_dst, 16, 0, 0);
+#else
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(window, (lds_void_t*)lds_dst, 16, (int)voff, 0, 0, 0);
+#endif
+}
 
 // SYM selects the column ranges and the column side:
 //   SYM_OFF    ranges as given, row side only (the general sweep);
@@ -1148,6 +1202,7 @@ __global__ __launch_bounds__(TOPK_THREADS, TVBF_DMA_WGS) void cosine_topk_dma_ke
 #ifdef TVBF_DIAG_TIMELINE  // timing-only build: every wave sums the cycle-counter time of the phases of a k-block pair
     unsigned long long* dl_buf = reinterpret_cast<unsigned long long*>(a.gram);
     unsigned long long dl[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dl_prev = __builtin_readcyclecounter(), dl_pairs = 0, dl_tiles = 0;
+    unsigned long long dl_cand = 0, dl_pops = 0, dl_compact = 0;  // row side: scores offered to the lists, pop-loop trips, compactions
     const unsigned long long dl_start = dl_prev;
     const unsigned long long dl_wall0 = wall_clock64();  // 100 MHz, one counter for the whole device
 #define DL_MARK(i)                                               \
@@ -1252,14 +1307,10 @@ __global__ __launch_bounds__(TOPK_THREADS, TVBF_DMA_WGS) void cosine_topk_dma_ke
     };
     auto dma_tile = [&](int kb, float* buffer) {
         const char* cb = tile_ptr + (size_t)kb * (BK * 4);
+        const __amdgpu_buffer_rsrc_t window = dma_window(cb);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            // a copy made opaque: the widening to 64 bits stays next to the use (scalar base + 32-bit
-            // offset).  Laundering coff[i] in place saves the v_mov but measured 1.2 % slower.
-            unsigned off = coff[i];
-            asm volatile("" : "+v"(off));
-            __builtin_amdgcn_global_load_lds((global_cvoid_t)(cb + off),
-                                             (lds_void_t*)(buffer + i * 1024 + wave * 256), 16, 0, 0);
+            dma16(window, cb, coff[i], buffer + i * 1024 + wave * 256);
         }
     };
     const char* qbase = reinterpret_cast<const char*>(a.zq + TVBF_DIAG_QTILE(q0) * a.ld);
@@ -1284,6 +1335,7 @@ __global__ __launch_bounds__(TOPK_THREADS, TVBF_DMA_WGS) void cosine_topk_dma_ke
         constexpr int PER_STEP = 16 / TVBF_VMEM_GAP;  // memory instructions per 16-MFMA step
         const char* cbytes = reinterpret_cast<const char*>(cur);
         const char* cb = tile_ptr + (size_t)kb_next * (BK * 4);
+        const __amdgpu_buffer_rsrc_t window = dma_window(cb);
         const char* qb = qbase + (size_t)kb_next * (BK * 4);
         unsigned qo = qoff;
         asm volatile("" : "+v"(qo));
@@ -1309,12 +1361,7 @@ __global__ __launch_bounds__(TOPK_THREADS, TVBF_DMA_WGS) void cosine_topk_dma_ke
             for (int g = 0; g < PER_STEP; ++g) {
                 const int v = t * PER_STEP + g;
                 if (v < 4) {
-                    // a copy made opaque: the widening to 64 bits stays next to the use (scalar base +
-                    // 32-bit offset)
-                    unsigned off = coff[v];
-                    asm volatile("" : "+v"(off));
-                    __builtin_amdgcn_global_load_lds((global_cvoid_t)(cb + off),
-                                                     (lds_void_t*)(next_buf + v * 1024 + wave * 256), 16, 0, 0);
+                    dma16(window, cb, coff[v], next_buf + v * 1024 + wave * 256);
                 } else if (v < 8) {
                     q_next[v - 4] = *reinterpret_cast<const f32x4*>(qb + qo + (v - 4) * 32);
                 }
@@ -1387,6 +1434,18 @@ __global__ __launch_bounds__(TOPK_THREADS, TVBF_DMA_WGS) void cosine_topk_dma_ke
                     thr = fmaxf(thr, gbf);
                 }
             // ------------------------- epilogue (see cosine_tile_kernel) -------------------------
+#ifdef TVBF_DIAG_INF_THR  // timing-only build: every score is compared, none is ever kept
+            thr = INFINITY;
+#endif
+#ifdef TVBF_DIAG_NO_EPI  // timing-only build: the tile is computed and dropped
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[j][r]));
+            if (false) {
+#else
+            {
+#endif
             const ColRange& cr = ct >= rng0.tiles ? rng1 : rng0;
             const int64_t trow = (int64_t)(ct >= rng0.tiles ? ct - rng0.tiles : ct) * BN;
             const int64_t col0 = cr.col_base + trow;
@@ -1412,66 +1471,100 @@ __global__ __launch_bounds__(TOPK_THREADS, TVBF_DMA_WGS) void cosine_topk_dma_ke
                     for (int r = 0; r < 16; ++r)
                         if (32 * j + (r & 3) + 8 * (r >> 2) == rel_self) acc[j][r] = -INFINITY;
             }
+            // Scores that reach the row's threshold are queued per lane (value in the wave's
+            // scratch, register number in a 64-bit mask) over the WHOLE tile and handed to the
+            // lists by one pop loop: its trip count is the most any lane queued, not the number of
+            // register groups in which some lane queued one.  There is ONE pop loop (and one
+            // compaction) in the code: a lane holds eight scores; should one find more in a tile
+            // (the first tiles of a sweep, before the threshold has risen), the scan is repeated
+            // for the registers behind the last one it handed on.  Keeping this code small matters:
+            // the instruction cache is shared with the waves that are in the tile loop.
+            {
+                int done_upto = -1;  // this lane's registers 0 .. done_upto (16 j + r) have been dealt with
+                bool again;
+#pragma nounroll
+                do {
+                    u64 rbits = 0ull;
+                    int rqueued = 0;
+                    bool overflow = false;
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
+                    for (int j = 0; j < NJ; ++j) {
 #pragma unroll
-                for (int r0 = 0; r0 < 16; r0 += DMA_SLOTS) {
-                    unsigned bits = 0u;
-                    int queued = 0;
+                        for (int g = 0; g < 4; ++g) {
+                            // four registers at a time: their largest score against the threshold first
+                            // (two v_max3 and one compare instead of four compares and four branches)
+                            const float top4 = fmaxf(fmaxf(acc[j][4 * g], acc[j][4 * g + 1]), fmaxf(acc[j][4 * g + 2], acc[j][4 * g + 3]));
+                            if (__any(top4 >= thr)) {
 #pragma unroll
-                    for (int r = r0; r < r0 + DMA_SLOTS; ++r) {
-                        if (acc[j][r] >= thr) {
-                            asm volatile("");  // keeps a real branch around the block
-                            scratch[queued * 64 + lane] = acc[j][r];
-                            ++queued;
-                            bits |= 1u << r;
-                        }
-                    }
-                    if (__any(bits != 0u)) {
-                        int slot = 0;
-                        while (__any(bits != 0u)) {
-                            const bool has = bits != 0u;
-                            const int r = has ? __builtin_ctz(bits) : 0;
-                            bits &= bits - 1u;
-                            const float v = scratch[slot * 64 + lane];
-                            ++slot;
-                            const int c = (int)col0 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * half;
-                            const u64 key = make_key(v, c);
-                            bool cand = has && v >= thr && key > mkey;
-                            while (__any(cand)) {
-                                if (cand) {
-                                    const unsigned pos = atomicAdd(my_cnt, 1u);
-                                    if (pos < (unsigned)a.cap) {
-                                        my_buf[pos] = key;
-                                        cand = false;
+                                for (int u = 0; u < 4; ++u) {
+                                    const int r = 4 * g + u;
+                                    if (acc[j][r] >= thr && 16 * j + r > done_upto) {
+                                        asm volatile("");  // keeps a real branch around the block
+                                        if (rqueued < DMA_SLOTS) {
+                                            scratch[rqueued * 64 + lane] = acc[j][r];
+                                            ++rqueued;
+                                            rbits |= 1ull << (16 * j + r);
+                                        } else {
+                                            overflow = true;
+                                        }
                                     }
-                                }
-                                u64 full = __ballot(cand);
-                                if (full) {
-                                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                                    __builtin_amdgcn_wave_barrier();
-                                    while (full) {
-                                        const int l = (int)__builtin_ctzll(full) & 31;
-                                        const int row = wave * 32 + l;
-                                        const int64_t qr = q0 + row;
-                                        if (LIST_GLOBAL)
-                                            merge_row_global(buf_all + (size_t)row * a.cap, cnt_all + row, mkey_all + row,
-                                                             a.partial + ((int64_t)split * a.nq + qr) * a.k,
-                                                             merge_scr + (size_t)wave * (a.k + a.cap), a.k, a.cap, lane,
-                                                             a.bound + qr, sentinel_key(a.min_similarity));
-                                        else
-                                            compact_row(buf_all + (size_t)row * a.cap, cnt_all + row, mkey_all + row,
-                                                        a.k, a.cap, lane, qr < a.nq ? a.bound + qr : nullptr);
-                                        full &= ~((1ull << l) | (1ull << (l + 32)));
-                                    }
-                                    mkey = *my_mkey;
-                                    thr = fmaxf(ordered_to_f32((uint32_t)(mkey >> 32)), gbf);
-                                    cand = cand && v >= thr && key > mkey;
                                 }
                             }
                         }
                     }
-                }
+                    if (!__any(rqueued > 0)) break;  // (no overflow without a queued score)
+                    done_upto = overflow ? 63 - (int)__builtin_clzll(rbits) : 63;
+                    again = __any(overflow);
+                    int slot = 0;
+                    while (__any(rbits != 0ull)) {
+                        const bool has = rbits != 0ull;
+                        const int idx = has ? __builtin_ctzll(rbits) : 0;  // 16 j + r
+                        rbits &= rbits - 1ull;
+                        const float v = scratch[slot * 64 + lane];
+                        ++slot;
+                        const int c = (int)col0 + 2 * (idx & 48) + (idx & 3) + 2 * (idx & 12) + 4 * half;  // 32 j + (r & 3) + 8 (r >> 2)
+                        const u64 key = make_key(v, c);
+                        bool cand = has && v >= thr && key > mkey;
+#ifdef TVBF_DIAG_TIMELINE
+                        dl_cand += __builtin_popcountll(__ballot(cand));
+                        ++dl_pops;
+#endif
+                        while (__any(cand)) {
+                            if (cand) {
+                                const unsigned pos = atomicAdd(my_cnt, 1u);
+                                if (pos < (unsigned)a.cap) {
+                                    my_buf[pos] = key;
+                                    cand = false;
+                                }
+                            }
+                            u64 full = __ballot(cand);
+                            if (full) {
+                                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                                __builtin_amdgcn_wave_barrier();
+                                while (full) {
+#ifdef TVBF_DIAG_TIMELINE
+                                    ++dl_compact;
+#endif
+                                    const int l = (int)__builtin_ctzll(full) & 31;
+                                    const int row = wave * 32 + l;
+                                    const int64_t qr = q0 + row;
+                                    if (LIST_GLOBAL)
+                                        merge_row_global(buf_all + (size_t)row * a.cap, cnt_all + row, mkey_all + row,
+                                                         a.partial + ((int64_t)split * a.nq + qr) * a.k,
+                                                         merge_scr + (size_t)wave * (a.k + a.cap), a.k, a.cap, lane,
+                                                         a.bound + qr, sentinel_key(a.min_similarity));
+                                    else
+                                        compact_row(buf_all + (size_t)row * a.cap, cnt_all + row, mkey_all + row,
+                                                    a.k, a.cap, lane, qr < a.nq ? a.bound + qr : nullptr);
+                                    full &= ~((1ull << l) | (1ull << (l + 32)));
+                                }
+                                mkey = *my_mkey;
+                                thr = fmaxf(ordered_to_f32((uint32_t)(mkey >> 32)), gbf);
+                                cand = cand && v >= thr && key > mkey;
+                            }
+                        }
+                    }
+                } while (again);
             }
             if (COLSIDE) {
                 // ---- column side: the same scores seen from the column shows.  Register r of
@@ -1547,6 +1640,7 @@ __global__ __launch_bounds__(TOPK_THREADS, TVBF_DMA_WGS) void cosine_topk_dma_ke
                     }
                 }
             }
+            }
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -1596,6 +1690,8 @@ __global__ __launch_bounds__(TOPK_THREADS, TVBF_DMA_WGS) void cosine_topk_dma_ke
         for (int i = 0; i < 8; ++i) o[i] = dl[i];
         o[8] = dl_pairs;
         o[9] = dl_tiles;
+        o[14] = dl_cand;
+        o[15] = dl_pops | (dl_compact << 32);
         o[10] = __builtin_readcyclecounter() - dl_start;
         o[11] = dl_wall0;
         o[12] = wall_clock64();
@@ -1744,12 +1840,10 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tri_dma_kernel(TriArgs
     };
     auto dma_tile = [&](int kb, float* buffer) {
         const char* cb = tile_ptr + (size_t)kb * (BK * 4);
+        const __amdgpu_buffer_rsrc_t window = dma_window(cb);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            unsigned off = coff[i];
-            asm volatile("" : "+v"(off));
-            __builtin_amdgcn_global_load_lds((global_cvoid_t)(cb + off),
-                                             (lds_void_t*)(buffer + i * 1024 + wave * 256), 16, 0, 0);
+            dma16(window, cb, coff[i], buffer + i * 1024 + wave * 256);
         }
     };
     const char* qbase = reinterpret_cast<const char*>(a.z + q0 * a.ld);
@@ -1767,6 +1861,7 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tri_dma_kernel(TriArgs
         constexpr int PER_STEP = 16 / TVBF_VMEM_GAP;  // memory instructions per 16-MFMA step
         const char* cbytes = reinterpret_cast<const char*>(cur);
         const char* cb = tile_ptr + (size_t)kb_next * (BK * 4);
+        const __amdgpu_buffer_rsrc_t window = dma_window(cb);
         const char* qb = qbase + (size_t)kb_next * (BK * 4);
         unsigned qo = qoff;
         asm volatile("" : "+v"(qo));
@@ -1792,12 +1887,7 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tri_dma_kernel(TriArgs
             for (int g = 0; g < PER_STEP; ++g) {
                 const int v = t * PER_STEP + g;
                 if (v < 4) {
-                    // a copy made opaque: the widening to 64 bits stays next to the use (scalar base +
-                    // 32-bit offset)
-                    unsigned off = coff[v];
-                    asm volatile("" : "+v"(off));
-                    __builtin_amdgcn_global_load_lds((global_cvoid_t)(cb + off),
-                                                     (lds_void_t*)(next_buf + v * 1024 + wave * 256), 16, 0, 0);
+                    dma16(window, cb, coff[v], next_buf + v * 1024 + wave * 256);
                 } else if (v < 8) {
                     q_next[v - 4] = *reinterpret_cast<const f32x4*>(qb + qo + (v - 4) * 32);
                 }
