@@ -62,4 +62,23 @@ pops = (raw[..., 15].astype(np.int64) & 0xFFFFFFFF).sum()
 compact = (raw[..., 15].astype(np.int64) >> 32).sum()
 print(f"row side per tile and wave: {cand / tiles:.2f} scores offered to the lists, {pops / tiles:.2f} trips of the pop loop, "
       f"{compact / tiles:.3f} compactions; per row and sweep: {cand / n:.0f} offered, {compact / n:.1f} compactions")
+w0, w1 = raw[..., 11], raw[..., 12]  # constant-rate clock (100 MHz) at a wave's start and end
+t0_, span = w0.min(), w1.max() - w0.min()
+print(f"waves start {100 * (w0.mean() - t0_) / span:.2f} % (latest {100 * (w0.max() - t0_) / span:.2f} %) into the kernel and end at "
+      f"{100 * (w1.mean() - t0_) / span:.2f} % on average (earliest {100 * (w1.min() - t0_) / span:.2f} %): "
+      f"{100 * (w1 - w0).sum() / (span * w0.size):.2f} % of wave slots x time is occupied")
+nwg = len(raw)
+end_wg = (w1.max(axis=1) - t0_) / span
+print(f"workgroups end at (share of the kernel's duration): first half of the grid {end_wg[:nwg // 2].mean():.3f}, second half "
+      f"{end_wg[nwg // 2:].mean():.3f}; by blockIdx % 8: " + " ".join(f"{end_wg[x::8].mean():.3f}" for x in range(8)))
+hw = raw[:, 0, 13].astype(np.int64)
+cu_key = ((hw >> 32) & 0xF) * 4096 + (hw & 0xFFFFFFFF & 0x3F00) + ((hw >> 13) & 0x7) * 16 * 0  # XCC, SE/SH/CU bits of HW_ID
+cu_key = ((hw >> 32) & 0xF) * 65536 + ((hw >> 8) & 0xF) + (((hw >> 12) & 0x1) << 4) + (((hw >> 13) & 0x7) << 5)
+ends = {}
+for key, e in zip(cu_key, end_wg):
+    ends.setdefault(int(key), []).append(float(e))
+pairs_ = [sorted(v) for v in ends.values() if len(v) == 2]
+if pairs_:
+    first = np.mean([v[0] for v in pairs_]); second = np.mean([v[1] for v in pairs_])
+    print(f"{len(ends)} compute units seen, {len(pairs_)} with two workgroups: the first to finish ends at {first:.3f}, the other at {second:.3f}")
 print(f"in the loop: {100 * tot.sum() / raw[..., 10].sum():.1f} % of the waves' lifetime")

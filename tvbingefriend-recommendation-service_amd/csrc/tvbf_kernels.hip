@@ -1579,11 +1579,44 @@ __global__ __launch_bounds__(TOPK_THREADS, TVBF_DMA_WGS) void cosine_topk_dma_ke
                 const unsigned my_row = (unsigned)(a.q_row0 + q0 + lrow);
                 // Scores that reach their column's bound are queued per lane (value in the wave's
                 // scratch, position in a 64-bit mask) over the WHOLE tile and handed on by one pop
-                // loop; a lane holds eight, so the queue is emptied early once a lane passes four
-                // (a group of four registers adds at most four).
-                u64 cbits = 0ull;
-                int cqueued = 0;
-                auto col_pop = [&]() {
+                // loop -- one in the code, as on the row side: a lane holds eight scores, and if
+                // one finds more in a tile the scan is repeated behind the last one handed on.
+                int done_upto = -1;  // this lane's registers 0 .. done_upto (16 j + r) have been dealt with
+                bool again;
+#pragma nounroll
+                do {
+                    u64 cbits = 0ull;
+                    int cqueued = 0;
+                    bool overflow = false;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 ct = *reinterpret_cast<const f32x4*>(cbound + 32 * j + 8 * g + 4 * half);
+                            // four registers at a time: one branch for the four compares
+                            const bool hit4 = (acc[j][4 * g] >= ct[0]) | (acc[j][4 * g + 1] >= ct[1]) |
+                                              (acc[j][4 * g + 2] >= ct[2]) | (acc[j][4 * g + 3] >= ct[3]);
+                            if (__any(hit4)) {
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) {
+                                    const int r = 4 * g + u;
+                                    if (acc[j][r] >= ct[u] && 16 * j + r > done_upto) {
+                                        asm volatile("");  // keeps a real branch around the block
+                                        if (cqueued < DMA_SLOTS) {
+                                            scratch[cqueued * 64 + lane] = acc[j][r];
+                                            ++cqueued;
+                                            cbits |= 1ull << (16 * j + r);
+                                        } else {
+                                            overflow = true;
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    if (!__any(cqueued > 0)) break;  // (no overflow without a queued score)
+                    done_upto = overflow ? 63 - (int)__builtin_clzll(cbits) : 63;
+                    again = __any(overflow);
                     int slot = 0;
                     bool pend = false;  // this lane's direct append completed a window of a show's buffer
                     unsigned pend_row = 0u, pend_w0 = 0u;
@@ -1609,36 +1642,13 @@ __global__ __launch_bounds__(TOPK_THREADS, TVBF_DMA_WGS) void cosine_topk_dma_ke
                             }
                         }
                     }
-                    cqueued = 0;
                     u64 todo = __ballot(pend);  // the scratch is free again: refresh those shows' bounds
                     while (todo) {
                         const int l = (int)__builtin_ctzll(todo);
                         todo &= todo - 1ull;
                         col_refresh_bound(a, __shfl(pend_row, l, 64), __shfl(pend_w0, l, 64), reinterpret_cast<u64*>(scratch), lane);
                     }
-                };
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 ct = *reinterpret_cast<const f32x4*>(cbound + 32 * j + 8 * g + 4 * half);
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int r = 4 * g + u;
-                            if (acc[j][r] >= ct[u]) {
-                                asm volatile("");  // keeps a real branch around the block
-                                scratch[cqueued * 64 + lane] = acc[j][r];
-                                ++cqueued;
-                                cbits |= 1ull << (16 * j + r);
-                            }
-                        }
-                        if (j == NJ - 1 && g == 3) {
-                            if (__any(cqueued > 0)) col_pop();
-                        } else if (__any(cqueued > 4)) {
-                            col_pop();
-                        }
-                    }
-                }
+                } while (again);
             }
             }
 #pragma unroll
