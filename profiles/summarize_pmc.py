@@ -38,7 +38,8 @@ suffix = {"plain": "", "symmetric": "_symmetric", "matrix": "_matrix"}[mode]
 wl = f"n{args.n // 1000}k_d{args.d}_k{args.k}" + ("" if args.data == "hybrid" else f"_{args.data}")
 res = {}
 for name in ("sq1", "sq2", "tcc1", "tcc2"):
-    f = glob.glob(f"{pmc}/{name}/**/*counter_collection.csv", recursive=True)
+    # the newest file: a directory merged from several collections keeps the older ones
+    f = sorted(glob.glob(f"{pmc}/{name}/**/*counter_collection.csv", recursive=True), key=lambda x: Path(x).stat().st_mtime, reverse=True)
     agg, calls = collections.defaultdict(float), collections.Counter()
     for r in csv.DictReader(open(f[0])):
         for kern in KERNELS:
