@@ -22,7 +22,12 @@
  *   - the library allocates no device memory: scratch comes in through the
  *     `workspace` argument, sized by the matching *_workspace_bytes() call;
  *   - no global mutable state: concurrent calls from different host threads
- *     on different streams/devices are safe.
+ *     on different streams/devices are safe.  Two exceptions, both stated where
+ *     they apply: tvbf_cosine_topk_static_f32 works in a per-device scratch
+ *     array that the library owns (overlapping calls on one GPU race), and a
+ *     handful of TVBF_* environment variables are read on every call as tuning
+ *     and diagnostic switches -- they select among routes that return the same
+ *     lists (tested bit for bit), never a different result.
  */
 #ifndef TVBF_H
 #define TVBF_H
