@@ -404,6 +404,10 @@ __device__ static inline void merge_row_global(u64* stg, unsigned* cnt, u64* mke
     for (int i = lane; i < valid; i += 64) scr[k + i] = stg[i];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    // The list arrives sorted (descending, keys unique, sentinels last), only the staged keys are in
+    // arrival order.  So a list key's rank is its index plus the number of staged keys above it, and
+    // a staged key's rank is the number of list keys above it -- a binary search -- plus the number
+    // of staged keys above it: at most `cap` compares per key instead of k + cap.
     const int m = k + valid;
     u64 my[3];
     int rk[3];
@@ -415,25 +419,43 @@ __device__ static inline void merge_row_global(u64* stg, unsigned* cnt, u64* mke
         real[u] = i < m && (uint32_t)my[u] != 0u;  // sentinels are not ranked
         rk[u] = 0;
     }
-    int i = 0;
+    const int slots = (m + 63) >> 6;  // uniform: 64-key groups in use (2 for k = 50, 3 only above k + cap = 128)
+    const u64* staged = scr + k;
+    int t = 0;
 #pragma nounroll
-    for (; i + 8 <= m; i += 8) {
+    for (; t + 8 <= valid; t += 8) {
         u64 o[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) o[u] = scr[i + u];
+        for (int u = 0; u < 8; ++u) o[u] = staged[t + u];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             rk[0] += o[u] > my[0] ? 1 : 0;
-            rk[1] += o[u] > my[1] ? 1 : 0;
-            rk[2] += o[u] > my[2] ? 1 : 0;
+            if (slots > 1) rk[1] += o[u] > my[1] ? 1 : 0;
+            if (slots > 2) rk[2] += o[u] > my[2] ? 1 : 0;
         }
     }
 #pragma nounroll
-    for (; i < m; ++i) {
-        const u64 o = scr[i];
+    for (; t < valid; ++t) {
+        const u64 o = staged[t];
         rk[0] += o > my[0] ? 1 : 0;
         rk[1] += o > my[1] ? 1 : 0;
         rk[2] += o > my[2] ? 1 : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        if (u >= slots) break;
+        const int i = lane + 64 * u;
+        if (i < k) {
+            rk[u] += i;  // list key: the i keys in front of it are above it
+        } else if (__any(i >= k && i < m)) {  // staged keys in this group: list keys above each, by bisection
+            int above = 0;
+#pragma unroll
+            for (int step = 64; step >= 1; step >>= 1) {  // k <= 100 < 128
+                const int probe = above + step;
+                if (probe <= k && scr[probe - 1] > my[u]) above = probe;
+            }
+            rk[u] += above;
+        }
     }
     int n_real = 0;
 #pragma unroll
