@@ -346,6 +346,33 @@ __device__ static inline void compact_row(u64* buf, unsigned* cnt, u64* mkey, in
         __builtin_amdgcn_wave_barrier();
         return;
     }
+    if (valid <= 64) {  // one key per lane
+        const bool has = lane < valid;
+        const u64 my = has ? buf[lane] : 0ull;
+        int r = 0;
+        int i = 0;
+#pragma nounroll
+        for (; i + 8 <= valid; i += 8) {  // eight independent broadcast reads in flight
+            u64 o[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) o[u] = buf[i + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) r += o[u] > my ? 1 : 0;
+        }
+#pragma nounroll
+        for (; i < valid; ++i) r += buf[i] > my ? 1 : 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (has && r < k) buf[r] = my;
+        if (has && r == k - 1) {
+            *mkey = my;
+            if (gbound) atomicMax(reinterpret_cast<unsigned long long*>(gbound), (unsigned long long)my);
+        }
+        if (lane == 0) *cnt = (unsigned)(valid < k ? valid : k);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        return;
+    }
     const bool has0 = lane < valid, has1 = lane + 64 < valid;
     const u64 my0 = has0 ? buf[lane] : 0ull;
     const u64 my1 = has1 ? buf[lane + 64] : 0ull;
@@ -2116,6 +2143,10 @@ __global__ __launch_bounds__(256) void matrix_rows_topk_kernel(const float* __re
     __builtin_amdgcn_wave_barrier();
     u64 mkey = sentinel_key(min_similarity);
     float thr = min_similarity;
+    unsigned cnt = 0u;  // entries in the buffer (wave-uniform)
+    // 64 entries while they leave room for 28 new ones: a compaction of 64 keys (one per lane) costs
+    // a quarter of one of 128, and the threshold it raises is fresher
+    const unsigned cap = k + 28 <= 64 ? 64u : (unsigned)MROW_CAP;
     const float* s = m + row * ldm;
     const int64_t skip = exclude_self ? row : -1;
     // 512 scores per step (two 16-byte loads per lane); the loads of the next step are issued before
@@ -2146,19 +2177,26 @@ __global__ __launch_bounds__(256) void matrix_rows_topk_kernel(const float* __re
                 const float v = v4[u];
                 const u64 key = make_key(v, (int)(col_base + c + u));
                 bool cand = c + u < n && c + u != skip && v >= thr && key > mkey;
+                // the buffer belongs to this wave alone: the entry count is a wave-uniform register
+                // and the lanes that hold a candidate take consecutive slots (no LDS atomics)
 #pragma nounroll
-                while (__any(cand)) {
-                    if (cand) {
-                        const unsigned pos = atomicAdd(&cnt_all[wave], 1u);
-                        if (pos < (unsigned)MROW_CAP) {
-                            buf[pos] = key;
-                            cand = false;
-                        }
+                for (;;) {
+                    const u64 mask = __ballot(cand);
+                    if (!mask) break;
+                    const unsigned room = cap - cnt;
+                    const unsigned before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                    if (cand && before < room) {
+                        buf[cnt + before] = key;
+                        cand = false;
                     }
-                    if (__any(cand)) {  // buffer full: keep the k best, raise the threshold, retry the rest
+                    const unsigned total = (unsigned)__builtin_popcountll(mask);
+                    cnt += total < room ? total : room;
+                    if (total > room) {  // buffer full: keep the k best, raise the threshold, retry the rest
+                        if (lane == 0) cnt_all[wave] = cnt;
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                         __builtin_amdgcn_wave_barrier();
-                        compact_row(buf, &cnt_all[wave], &mkey_all[wave], k, MROW_CAP, lane, nullptr);
+                        compact_row(buf, &cnt_all[wave], &mkey_all[wave], k, (int)cap, lane, nullptr);
+                        cnt = __builtin_amdgcn_readfirstlane(cnt_all[wave]);
                         mkey = mkey_all[wave];
                         thr = fmaxf(ordered_to_f32((uint32_t)(mkey >> 32)), min_similarity);
                         cand = cand && v >= thr && key > mkey;
@@ -2169,9 +2207,10 @@ __global__ __launch_bounds__(256) void matrix_rows_topk_kernel(const float* __re
         cur[0] = nxt[0];
         cur[1] = nxt[1];
     }
+    if (lane == 0) cnt_all[wave] = cnt;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    compact_row(buf, &cnt_all[wave], &mkey_all[wave], k, MROW_CAP, lane, nullptr);
+    compact_row(buf, &cnt_all[wave], &mkey_all[wave], k, (int)cap, lane, nullptr);
     const int have = (int)cnt_all[wave];
     if (TO_SLOT) {
         for (int i = lane; i < k; i += 64) slot[row * k + i] = i < have ? buf[i] : sentinel_key(min_similarity);
