@@ -1444,7 +1444,11 @@ __global__ __launch_bounds__(TOPK_THREADS, TVBF_DMA_WGS) void cosine_topk_dma_ke
             // the barrier that ended the previous tile also completed the loads of set_tile; the
             // epilogue that reads cbound and appends to the queue is many barriers away
             if (tid < BN) {
+#ifdef TVBF_DIAG_COL_INF  // timing-only build: the column side compares every score and keeps none
+                cbound[tid] = INFINITY;
+#else
                 cbound[tid] = ordered_to_f32((uint32_t)(cb_key >> 32));
+#endif
                 cblo[tid] = (uint32_t)cb_key;
             }
             unsigned queued_cols = *lcnt;
@@ -1626,12 +1630,18 @@ __global__ __launch_bounds__(TOPK_THREADS, TVBF_DMA_WGS) void cosine_topk_dma_ke
                         for (int r = 0; r < 16; ++r) acc[j][r] = -INFINITY;
                 }
                 const unsigned my_row = (unsigned)(a.q_row0 + q0 + lrow);
+#ifdef TVBF_DIAG_COL_OFF  // timing-only build: no column side at all
+                constexpr bool col_side_on = false;
+#else
+                constexpr bool col_side_on = true;
+#endif
                 // Scores that reach their column's bound are queued per lane (value in the wave's
                 // scratch, position in a 64-bit mask) over the WHOLE tile and handed on by one pop
                 // loop -- one in the code, as on the row side: a lane holds eight scores, and if
                 // one finds more in a tile the scan is repeated behind the last one handed on.
                 int done_upto = -1;  // this lane's registers 0 .. done_upto (16 j + r) have been dealt with
                 bool again;
+                if (col_side_on)
 #pragma nounroll
                 do {
                     u64 cbits = 0ull;
