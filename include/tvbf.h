@@ -439,7 +439,12 @@ int tvbf_query_topk_f32(const float* Zq, int64_t nq, int64_t ldq, const int64_t*
 /*
  * Statistics of the strict upper triangle of Z Z^T -- mean, population standard
  * deviation, min, max, median -- without storing the matrix: three sweeps of the
- * tile engine (sums / extrema / radix histograms of the median's key).  Replaces
+ * tile engine (sums / extrema / radix histograms of the median's key); from 24,576
+ * shows on ONE sweep: the quantiles 0.48 and 0.52 of a sample of the pairs (every
+ * k-th show) bound a band of keys, the sweep counts the scores below the band and
+ * keeps those inside it (4 % of them) in the workspace, and the exact middle
+ * elements are selected from there -- the three sweeps run only if the band missed
+ * them.  Replaces
  * get_similarity_statistics (ml/similarity_computer.py:171-190, called four times by
  * scripts/compute_similarities.py:119-131) for catalogues whose n x n matrix does not
  * fit; values are the fp32 scores of tvbf_gram_f32, sums are float64.
@@ -451,6 +456,12 @@ int tvbf_query_topk_f32(const float* Zq, int64_t nq, int64_t ldq, const int64_t*
 size_t tvbf_gram_stats_workspace_bytes(int64_t n);
 int tvbf_gram_stats_f32(const float* Z, int64_t n, int64_t d, int64_t ld, double* out5,
                         void* workspace, size_t workspace_bytes, void* stream);
+/* What the last tvbf_gram_stats_f32 call on this workspace did (synchronises the stream; for
+ * tests and tuning; no counterpart in the reference).  out6 (host): [0] 1 = the radix sweeps ran
+ * (small catalogue, or the band missed a middle element or overflowed), 0 = the band route gave the
+ * median; [1] scores below the band, [2] equal to its lower key, [3] strictly inside (buffered),
+ * [4] equal to its upper key, [5] capacity of the buffer in keys. */
+int tvbf_gram_stats_inspect(const void* workspace, int64_t* out6, void* stream);
 
 #ifdef __cplusplus
 }

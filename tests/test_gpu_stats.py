@@ -1,4 +1,5 @@
-"""Statistics of the strict upper triangle of Z Z^T without the matrix (three tile sweeps)."""
+"""Statistics of the strict upper triangle of Z Z^T without the matrix: three tile sweeps (radix
+select), or one sweep that keeps the scores of a band around the median (large catalogues)."""
 
 from __future__ import annotations
 
@@ -72,3 +73,95 @@ def test_gram_stats_rejects_bad_arguments(pkg, device):
     # an all-zero matrix: every statistic is 0
     got = engine.gram_stats(z).cpu().numpy()
     assert np.all(got == 0)
+
+
+def _stats_both_routes(monkeypatch, engine, z):
+    """(radix route, band route, info of the band route) for the same Z."""
+    monkeypatch.setenv("TVBF_STATS_ROUTE", "radix")
+    radix = engine.gram_stats(z).cpu().numpy()
+    monkeypatch.setenv("TVBF_STATS_ROUTE", "band")
+    info = {}
+    band = engine.gram_stats(z, info=info).cpu().numpy()
+    return radix, band, info
+
+
+@pytest.mark.parametrize("n,d,kind", [(700, 64, "dense"), (1500, 256, "dense"), (2500, 192, "dense"), (4100, 128, "dense"),
+                                      (3000, 256, "hybrid"), (6000, 64, "dense")])
+def test_band_route_equals_radix_route(pkg, device, monkeypatch, n, d, kind):
+    """One sweep + selection inside the band's buffer: all five numbers bit for bit those of the
+    three radix sweeps (the sums are folded in the same order), and the band really was used."""
+    import torch
+
+    from tvbingefriend_recommendation_service_amd import engine
+
+    if kind == "dense":
+        x = dense_gaussian(n, d, seed=n + d)
+    else:
+        g, t, p, ty, la = hybrid_like_blocks(n, seed=n, d_genre=16, d_text=d - 48)
+        x = np.ascontiguousarray(np.hstack([g, t, p, ty, la]), dtype=np.float32)
+    z = engine.normalize_blocks(torch.from_numpy(x).to(device), [0, x.shape[1]], [1.0])
+    radix, band, info = _stats_both_routes(monkeypatch, engine, z)
+    assert np.array_equal(radix, band), (radix, band, info)
+    count = n * (n - 1) // 2
+    assert info["radix_sweeps"] == 0, info
+    assert info["below"] <= (count - 1) // 2 and info["buffered"] <= info["capacity"], info
+    assert info["buffered"] + info["equal_lo"] + info["equal_hi"] < 0.1 * count, info  # a band, not everything
+    # and against NumPy on the kernel's own fp32 scores
+    s32 = engine.gram(z).cpu().numpy().astype(np.float64)
+    ref32 = _ref_stats(s32)
+    assert band[2] == ref32[2] and band[3] == ref32[3] and band[4] == ref32[4]
+
+
+def test_band_route_ties_at_the_median(pkg, device, monkeypatch):
+    """One-hot rows: the scores are 0 or 1 and the median sits in a tie of millions -- both ends of
+    the band are that key, nothing needs buffering."""
+    import torch
+
+    from tvbingefriend_recommendation_service_amd import engine
+
+    n, d = 3000, 64
+    rng = np.random.default_rng(9)
+    x = np.zeros((n, d), dtype=np.float32)
+    x[np.arange(n), rng.integers(0, 12, n)] = 1.0
+    z = engine.normalize_blocks(torch.from_numpy(x).to(device), [0, d], [1.0])
+    radix, band, info = _stats_both_routes(monkeypatch, engine, z)
+    assert np.array_equal(radix, band) and band[4] == 0.0, (radix, band, info)
+    assert info["radix_sweeps"] == 0 and info["buffered"] == 0 and info["equal_lo"] > 0.8 * n * (n - 1) / 2, info
+
+
+def test_band_route_falls_back_when_the_sample_misleads(pkg, device, monkeypatch):
+    """The sample is every second show; here those are all the same show (every sampled score is 1)
+    while the others are random: the band lies far from the median, the radix sweeps take over and
+    the numbers are still exact."""
+    import torch
+
+    from tvbingefriend_recommendation_service_amd import engine
+
+    n, d = 2600, 128
+    x = dense_gaussian(n, d, seed=77)
+    x[::2] = x[0]
+    z = engine.normalize_blocks(torch.from_numpy(x).to(device), [0, d], [1.0])
+    radix, band, info = _stats_both_routes(monkeypatch, engine, z)
+    assert info["radix_sweeps"] == 1, info
+    assert np.array_equal(radix, band), (radix, band, info)
+    s32 = engine.gram(z).cpu().numpy().astype(np.float64)
+    ref32 = _ref_stats(s32)
+    assert band[2] == ref32[2] and band[3] == ref32[3] and band[4] == ref32[4]
+
+
+def test_band_route_is_the_default_for_large_catalogues(pkg, device, monkeypatch):
+    """n = 30,000 takes the band route by itself (sample: every second show); same numbers as the
+    radix sweeps."""
+    import torch
+
+    from tvbingefriend_recommendation_service_amd import engine
+
+    n, d = 30_000, 64
+    z = engine.normalize_blocks(torch.from_numpy(dense_gaussian(n, d, seed=5)).to(device), [0, d], [1.0])
+    monkeypatch.delenv("TVBF_STATS_ROUTE", raising=False)
+    info = {}
+    band = engine.gram_stats(z, info=info).cpu().numpy()
+    assert info["radix_sweeps"] == 0 and 0.02 * n * n / 2 < info["buffered"] < 0.06 * n * n / 2, info
+    monkeypatch.setenv("TVBF_STATS_ROUTE", "radix")
+    radix = engine.gram_stats(z).cpu().numpy()
+    assert np.array_equal(radix, band), (radix, band, info)

@@ -1788,7 +1788,31 @@ __global__ __launch_bounds__(TOPK_THREADS, TVBF_DMA_WGS) void cosine_topk_dma_ke
 // Lane = query row (wave w owns rows 32 w .. 32 w + 31 of the row block), register (j, r) =
 // column 32 j + 8 (r >> 2) + 4 half + (r & 3) of the tile.
 // --------------------------------------------------------------------------
-enum { TRI_STORE = 0, TRI_STATS = 1 };
+// Workspace of the statistics mode (tvbf_gram_stats_f32).  The radix select works on `hist`,
+// `prefix` and `rank`; the band route (see cosine_tri_dma_kernel<TRI_BAND>) adds the band's keys,
+// what the band sweep counted and where the two middle elements turned out to be.
+struct GramStatsWs {
+    unsigned hist[2 * ST_BINS];
+    unsigned prefix[2];
+    unsigned long long rank[2];  // 0-based ascending ranks of the two elements looked for
+    unsigned band_lo, band_hi;   // ordered keys: the sample's quantiles on either side of the median
+    unsigned fallback;           // 1: the band did not hold both middle elements (or overflowed): radix sweeps run
+    unsigned where[2];           // middle element t: 0 = equals band_lo, 1 = in the buffer (rank[t] inside it), 2 = equals band_hi
+    unsigned median_key[2];
+    unsigned long long below, eq_lo, eq_hi, buffered;  // scores below the band, equal to its ends, strictly inside (appended)
+    unsigned long long buf_cap;
+    double part[1];              // [workgroups][4], variable length
+};
+
+// TRI_BAND: the statistics sweep that needs no second look at the scores.  The caller knows two keys
+// lo <= hi that very probably enclose the median (quantiles of a sample of the pairs).  One sweep
+// over all pairs adds up sum, sum of squares and extrema as TRI_STATS level 0 does, counts the scores
+// below lo, equal to lo and equal to hi, and appends every key strictly between them to a buffer in
+// global memory (staged per wave in LDS, one global atomic per 512 keys).  If the two middle ranks
+// fall inside [lo, hi] and the buffer held everything, the median is selected from the buffer --
+// exactly; otherwise the radix sweeps run as before.
+enum { TRI_STORE = 0, TRI_STATS = 1, TRI_BAND = 2 };
+constexpr int BAND_STAGE = 512;  // keys a wave stages in LDS before it appends them to the buffer
 
 struct TriArgs {
     const float* z;
@@ -1801,6 +1825,9 @@ struct TriArgs {
     unsigned* st_hist;
     const unsigned* st_prefix;
     int st_level;
+    const unsigned* st_gate;    // TRI_STATS: when given, the sweep runs only if this word is non-zero
+    GramStatsWs* bn_ws;         // TRI_BAND
+    unsigned* bn_buf;           // TRI_BAND: bn_ws->buf_cap keys
 };
 
 // tiles of the row blocks before row block rb
@@ -1835,12 +1862,34 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tri_dma_kernel(TriArgs
     float st_min = INFINITY, st_max = -INFINITY;
     unsigned st_pre0 = 0u, st_pre1 = 0u;
     if (EPI == TRI_STATS) {
+        if (a.st_gate && __hip_atomic_load(a.st_gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
         for (int i = tid; i < 2 * ST_BINS; i += TOPK_THREADS) st_lds[i] = 0u;
         if (a.st_level > 0) {
             st_pre0 = a.st_prefix[0];
             st_pre1 = a.st_prefix[1];
         }
     }
+    // TRI_BAND: the band's keys, this lane's counts, this wave's staged keys (LDS: [4][BAND_STAGE + 64])
+    unsigned bn_lo = 0u, bn_hi = 0u, bn_below = 0u, bn_eqlo = 0u, bn_eqhi = 0u, bn_staged = 0u;
+    unsigned* const bn_stage = st_lds + wave * (BAND_STAGE + 64);
+    if (EPI == TRI_BAND) {
+        bn_lo = a.bn_ws->band_lo;
+        bn_hi = a.bn_ws->band_hi;
+    }
+    auto band_flush = [&]() {  // wave-uniform: the staged keys go to the buffer (what does not fit is only counted)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        unsigned long long base = 0ull;
+        if (lane == 0) base = atomicAdd(&a.bn_ws->buffered, (unsigned long long)bn_staged);
+        base = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(base >> 32)) << 32) |
+               __builtin_amdgcn_readfirstlane((unsigned)base);
+        const unsigned long long cap = a.bn_ws->buf_cap;
+        for (unsigned i = lane; i < bn_staged; i += 64)
+            if (base + i < cap) a.bn_buf[base + i] = bn_stage[i];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        bn_staged = 0u;
+    };
 
 #ifdef TVBF_TRI_STAGGER  // experiment: the second workgroup of a compute unit starts TVBF_TRI_STAGGER x 512 cycles late
     if ((int)blockIdx.x >= a.items / 2)
@@ -2053,6 +2102,26 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tri_dma_kernel(TriArgs
                     int rel_row = (int)(qr - col0) - 4 * half, rel_end = (int)(a.n - col0) - 4 * half;
                     if (qr >= a.n) rel_row = 1 << 20;  // a repeated row past the end: nothing counts
                     asm volatile("" : "+v"(rel_row), "+v"(rel_end));
+                    auto fold_band = [&](float v, bool counts) {  // called by all lanes together
+                        const unsigned key = f32_to_ordered(v);
+                        if (counts) {
+                            st_sum += (double)v;
+                            st_sq += (double)v * (double)v;
+                            st_min = fminf(st_min, v);
+                            st_max = fmaxf(st_max, v);
+                            bn_below += key < bn_lo ? 1u : 0u;
+                            bn_eqlo += key == bn_lo ? 1u : 0u;
+                            bn_eqhi += (key == bn_hi && bn_hi != bn_lo) ? 1u : 0u;
+                        }
+                        const bool inside = counts && key > bn_lo && key < bn_hi;
+                        const u64 m = __ballot(inside);
+                        if (m) {
+                            if (inside)
+                                bn_stage[bn_staged + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = key;
+                            bn_staged += (unsigned)__builtin_popcountll(m);
+                            if (bn_staged >= (unsigned)BAND_STAGE) band_flush();
+                        }
+                    };
                     auto fold = [&](float v) {
                         const unsigned key = f32_to_ordered(v);
                         if (a.st_level == 0) {
@@ -2067,7 +2136,15 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tri_dma_kernel(TriArgs
                             if (pre == st_pre1 && st_pre1 != st_pre0) atomicAdd(&st_lds[ST_BINS + ((key >> sh) & mask)], 1u);
                         }
                     };
-                    if (interior) {
+                    if (EPI == TRI_BAND) {
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int rel = 32 * j + 8 * (r >> 2) + (r & 3);  // column - col0 - 4 half
+                                fold_band(acc[j][r], interior || (rel > rel_row && rel < rel_end));
+                            }
+                    } else if (interior) {
 #pragma unroll
                         for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -2093,15 +2170,32 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tri_dma_kernel(TriArgs
     }
     }  // segments
 
-    if (EPI == TRI_STATS) {
+    if (EPI == TRI_BAND) {
+        if (bn_staged) band_flush();
+        // counts: lanes -> wave (butterfly) -> global, integer adds in any order
+        unsigned long long c0 = bn_below, c1 = bn_eqlo, c2 = bn_eqhi;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            c0 += __shfl_xor(c0, off, 64);
+            c1 += __shfl_xor(c1, off, 64);
+            c2 += __shfl_xor(c2, off, 64);
+        }
+        if (lane == 0) {
+            if (c0) atomicAdd(&a.bn_ws->below, c0);
+            if (c1) atomicAdd(&a.bn_ws->eq_lo, c1);
+            if (c2) atomicAdd(&a.bn_ws->eq_hi, c2);
+        }
+    }
+    if (EPI == TRI_STATS || EPI == TRI_BAND) {
         // every workgroup leaves its sums in its own slot (folded later in a fixed order) and adds
         // its histogram to the global one (integer adds: order does not matter)
         __syncthreads();
+        if (EPI == TRI_STATS)
         for (int i = tid; i < 2 * ST_BINS; i += TOPK_THREADS) {
             const unsigned v = st_lds[i];
             if (v) atomicAdd(&a.st_hist[i], v);
         }
-        if (a.st_level == 0) {
+        if ((EPI == TRI_BAND || a.st_level == 0) && a.st_part) {
             double* red = reinterpret_cast<double*>(st_lds + 2 * ST_BINS);  // [4][TOPK_THREADS]
             red[tid] = st_sum;
             red[TOPK_THREADS + tid] = st_sq;
@@ -2751,32 +2845,135 @@ __global__ __launch_bounds__(256) void query_select_kernel(const float* __restri
 // level-0 sweep (sums, extrema, first radix histogram), two more sweeps that
 // refine the median's key, small kernels in between that pick the bins.
 // --------------------------------------------------------------------------
-struct GramStatsWs {
-    unsigned hist[2 * ST_BINS];
-    unsigned prefix[2];
-    unsigned long long rank[2];  // 0-based ascending ranks of the two middle elements
-    double part[1];              // [workgroups][4], variable length
-};
-
-__global__ __launch_bounds__(256) void gram_stats_init_kernel(GramStatsWs* ws, unsigned long long count) {
+// radix select for the elements of ranks r0 and r1; `band`: the band route follows (its counters are cleared,
+// the final kernel takes the median it resolves unless it falls back to the radix sweeps)
+__global__ __launch_bounds__(256) void gram_stats_init_kernel(GramStatsWs* ws, unsigned long long r0,
+                                                              unsigned long long r1, int band,
+                                                              unsigned long long buf_cap) {
     for (int i = threadIdx.x; i < 2 * ST_BINS; i += 256) ws->hist[i] = 0u;
     if (threadIdx.x < 2) {
         ws->prefix[threadIdx.x] = 0u;
-        ws->rank[threadIdx.x] = threadIdx.x == 0 ? (count - 1) / 2 : count / 2;
+        ws->rank[threadIdx.x] = threadIdx.x == 0 ? r0 : r1;
+        ws->where[threadIdx.x] = 1u;
+        ws->median_key[threadIdx.x] = 0u;
+    }
+    if (threadIdx.x == 0) {
+        ws->band_lo = ws->band_hi = 0u;
+        ws->fallback = band ? 0u : 1u;
+        ws->below = ws->eq_lo = ws->eq_hi = ws->buffered = 0ull;
+        ws->buf_cap = buf_cap;
     }
 }
 
-__global__ __launch_bounds__(256) void gram_stats_pick_kernel(GramStatsWs* ws, int level) {
+// the sample's radix select is done: its two quantile keys become the band
+__global__ __launch_bounds__(64) void band_begin_kernel(GramStatsWs* ws) {
+    if (threadIdx.x == 0) {
+        const unsigned lo = ws->prefix[0], hi = ws->prefix[1];
+        ws->band_lo = lo < hi ? lo : hi;
+        ws->band_hi = lo < hi ? hi : lo;
+    }
+}
+
+// after the band sweep: where are the two middle elements (ranks m0 <= m1 of all `count` scores)?
+__global__ __launch_bounds__(256) void band_check_kernel(GramStatsWs* ws, unsigned long long m0, unsigned long long m1) {
+    for (int i = threadIdx.x; i < 2 * ST_BINS; i += 256) ws->hist[i] = 0u;
+    if (threadIdx.x == 0) {
+        unsigned fb = 0u;
+        const unsigned long long below = ws->below, eq_lo = ws->eq_lo, eq_hi = ws->eq_hi, inside = ws->buffered;
+        for (int t = 0; t < 2; ++t) {
+            unsigned long long r = t == 0 ? m0 : m1;
+            unsigned where = 0u;
+            if (r < below) {
+                fb = 1u;
+            } else if ((r -= below) < eq_lo) {
+                where = 0u;
+            } else if ((r -= eq_lo) < inside) {
+                where = 1u;
+                if (inside > ws->buf_cap) fb = 1u;  // part of the band was only counted
+            } else if ((r -= inside) < eq_hi) {
+                where = 2u;
+            } else {
+                fb = 1u;
+            }
+            ws->where[t] = where;
+            ws->rank[t] = r;  // inside the buffer when where == 1
+            ws->prefix[t] = 0u;
+        }
+        ws->fallback = fb;
+    }
+}
+
+// one radix level over the buffered keys (the bookkeeping between the levels is gram_stats_pick_kernel's)
+__global__ __launch_bounds__(256) void band_hist_kernel(GramStatsWs* ws, const unsigned* __restrict__ buf, int level) {
+    __shared__ unsigned h[2 * ST_BINS];
+    if (__hip_atomic_load(&ws->fallback, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+    for (int i = threadIdx.x; i < 2 * ST_BINS; i += 256) h[i] = 0u;
+    __syncthreads();
+    unsigned long long m = ws->buffered;
+    if (m > ws->buf_cap) m = ws->buf_cap;
+    const unsigned pre0 = ws->prefix[0], pre1 = ws->prefix[1];
+    const int sh = st_shift(level), prev = level == 0 ? 32 : st_shift(level - 1);
+    const unsigned mask = (1u << st_bits(level)) - 1u;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < m; i += (unsigned long long)gridDim.x * 256) {
+        const unsigned key = buf[i];
+        if (level == 0) {
+            atomicAdd(&h[key >> sh], 1u);
+        } else {
+            const unsigned pre = key >> prev;
+            if (pre == pre0) atomicAdd(&h[(key >> sh) & mask], 1u);
+            if (pre == pre1 && pre1 != pre0) atomicAdd(&h[ST_BINS + ((key >> sh) & mask)], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * ST_BINS; i += 256)
+        if (h[i]) atomicAdd(&ws->hist[i], h[i]);
+}
+
+// the band route's median keys; if it failed, the radix select over all scores starts from scratch
+__global__ __launch_bounds__(256) void band_resolve_kernel(GramStatsWs* ws, unsigned long long m0, unsigned long long m1) {
+    for (int i = threadIdx.x; i < 2 * ST_BINS; i += 256) ws->hist[i] = 0u;
+    if (threadIdx.x < 2) {
+        const int t = threadIdx.x;
+        const unsigned where = ws->where[t];
+        ws->median_key[t] = where == 0u ? ws->band_lo : where == 2u ? ws->band_hi : ws->prefix[t];
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 && ws->fallback) {
+        ws->prefix[threadIdx.x] = 0u;
+        ws->rank[threadIdx.x] = threadIdx.x == 0 ? m0 : m1;
+    }
+}
+
+// `gate`: when given, the kernel does its work only if that word is non-zero
+__global__ __launch_bounds__(256) void gram_stats_pick_kernel(GramStatsWs* ws, int level, const unsigned* gate) {
     __shared__ unsigned new_prefix[2];
     __shared__ unsigned long long new_rank[2];
+    if (gate && __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
     const int t = threadIdx.x;
+    // the histograms in LDS with the sums of runs of eight bins beside them: a rank is located by
+    // walking 256 run sums and then 8 bins instead of 2048 dependent reads of global memory
+    __shared__ unsigned h_lds[2 * ST_BINS];
+    __shared__ unsigned long long run_sum[2][ST_BINS / 8];
+    for (int i = t; i < 2 * ST_BINS; i += 256) h_lds[i] = ws->hist[i];
+    __syncthreads();
+    for (int hsel = 0; hsel < 2; ++hsel) {
+        unsigned long long acc = 0;
+        for (int u = 0; u < 8; ++u) acc += h_lds[hsel * ST_BINS + 8 * t + u];
+        run_sum[hsel][t] = acc;
+    }
+    __syncthreads();
     if (t < 2) {
         const bool one_hist = level == 0 || ws->prefix[0] == ws->prefix[1];
-        const unsigned* h = ws->hist + ((t == 1 && !one_hist) ? ST_BINS : 0);
+        const int hsel = (t == 1 && !one_hist) ? 1 : 0;
+        const unsigned* h = h_lds + hsel * ST_BINS;
         const unsigned long long rank = ws->rank[t];
         unsigned long long cum = 0;
         const int bins = 1 << st_bits(level);
         int b = 0;
+        while (b + 8 < bins && cum + run_sum[hsel][b >> 3] <= rank) {  // whole runs below the rank
+            cum += run_sum[hsel][b >> 3];
+            b += 8;
+        }
         for (; b < bins - 1; ++b) {
             if (cum + h[b] > rank) break;
             cum += h[b];
@@ -2823,7 +3020,9 @@ __global__ __launch_bounds__(256) void gram_stats_final_kernel(const GramStatsWs
         out5[1] = sqrt(var);
         out5[2] = red[2][0];
         out5[3] = red[3][0];
-        out5[4] = 0.5 * ((double)ordered_to_f32(ws->prefix[0]) + (double)ordered_to_f32(ws->prefix[1]));
+        const unsigned k0 = ws->fallback ? ws->prefix[0] : ws->median_key[0];
+        const unsigned k1 = ws->fallback ? ws->prefix[1] : ws->median_key[1];
+        out5[4] = 0.5 * ((double)ordered_to_f32(k0) + (double)ordered_to_f32(k1));
     }
 }
 
@@ -4033,14 +4232,51 @@ static int gram_stats_chunk(int tiles) {
     return c < 16 ? 16 : c;
 }
 
-size_t tvbf_gram_stats_workspace_bytes(int64_t n) {
-    if (n < 2 || n > INT32_MAX - BN) return 0;
+// Band route of the statistics (one sweep over all pairs instead of three): from BAND_MIN_N shows
+// on.  The sample is every `stride`-th show (about BAND_SAMPLE_N of them), its quantiles
+// 0.5 -+ delta are the band, and the buffer holds count / 16 keys -- the band is expected to
+// hold 2 * delta = 4 % of the scores (measured at N = 100,000: 4.00 %, the median 97 M keys into
+// the 200 M buffered).  TVBF_STATS_ROUTE=radix|band overrides the choice
+// (band: from 512 shows on, for tests).
+constexpr int64_t BAND_MIN_N = 24576, BAND_SAMPLE_N = 12288;
+constexpr double BAND_DELTA = 0.02, BAND_DELTA_MIN = 0.004;
+constexpr size_t BAND_CAP_MAX = (size_t)1 << 29;  // keys (2 GiB)
+
+static size_t stats_band_cap(int64_t n) {  // keys
+    const unsigned long long count = (unsigned long long)n * (unsigned long long)(n - 1) / 2;
+    const unsigned long long cap = (count / 16 + 65536 + 63) / 64 * 64;
+    return (size_t)(cap < BAND_CAP_MAX ? cap : BAND_CAP_MAX);
+}
+
+// half width of the band in quantile units: 0.02 while the buffer (capped at 2 GiB) holds 2.5 x the
+// band, narrower above ~130,000 shows; below 0.004 (about 330,000 shows) the sample's quantiles
+// are not sharp enough and the radix sweeps run at once
+static double stats_band_delta(int64_t n) {
+    const double count = (double)n * (double)(n - 1) / 2;
+    const double d = 0.4 * (double)stats_band_cap(n) / count;
+    return d < BAND_DELTA ? d : BAND_DELTA;
+}
+
+static bool stats_band_route(int64_t n) {
+    if (const char* e = getenv("TVBF_STATS_ROUTE")) {
+        if (!strcmp(e, "radix")) return false;
+        if (!strcmp(e, "band")) return n >= 512;
+    }
+    return n >= BAND_MIN_N && stats_band_delta(n) >= BAND_DELTA_MIN;
+}
+
+static size_t stats_head_bytes(int64_t n) {  // the bookkeeping struct and the per-workgroup sums
     const int tiles = tiles_of(n);
     const int chunk = gram_stats_chunk(tiles);
     size_t wgs = (size_t)tiles * (size_t)((tiles + chunk - 1) / chunk);
     const size_t tri = (size_t)tri_items(tri_prefix(tiles, tiles), device_cus());  // the LDS-DMA sweep's workgroups
     if (tri > wgs) wgs = tri;
     return (sizeof(GramStatsWs) + wgs * 4 * sizeof(double) + 255) / 256 * 256;
+}
+
+size_t tvbf_gram_stats_workspace_bytes(int64_t n) {
+    if (n < 2 || n > INT32_MAX - BN) return 0;
+    return stats_head_bytes(n) + (stats_band_route(n) ? stats_band_cap(n) * sizeof(unsigned) : 0);
 }
 
 int tvbf_gram_stats_f32(const float* Z, int64_t n, int64_t d, int64_t ld, double* out5, void* workspace,
@@ -4058,9 +4294,60 @@ int tvbf_gram_stats_f32(const float* Z, int64_t n, int64_t d, int64_t ld, double
     const int tiles = tiles_of(n);
     const unsigned long long count = (unsigned long long)n * (unsigned long long)(n - 1) / 2;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gram_stats_init_kernel, dim3(1), dim3(256), 0, st, ws, count);
+    const unsigned long long m0 = (count - 1) / 2, m1 = count / 2;  // the middle elements
     int64_t wgs = 0;
-    if (topk_use_dma(d)) {  // LDS-DMA tile loop, the tiles on and right of the diagonal in equal stretches
+    const unsigned* no_gate = nullptr;
+    // the sample of the band route: every stride-th show, as a view with a longer leading dimension
+    int64_t stride = n / BAND_SAMPLE_N < 2 ? 2 : n / BAND_SAMPLE_N;
+    while (stride > 1 && ld * stride > (INT32_MAX / 4) / (BM + BN)) --stride;
+    if (topk_use_dma(d) && stats_band_route(n) && stride >= 2) {
+        const size_t lds = 2 * ST_BINS * sizeof(unsigned) + 4 * TOPK_THREADS * sizeof(double);
+        static_assert(4 * (BAND_STAGE + 64) <= 2 * ST_BINS, "the staged keys take the histograms' place in LDS");
+        const int64_t ns = (n + stride - 1) / stride;
+        const unsigned long long count_s = (unsigned long long)ns * (unsigned long long)(ns - 1) / 2;
+        const double delta = stats_band_delta(n);
+        unsigned long long r_lo = (unsigned long long)((0.5 - delta) * (double)count_s);
+        unsigned long long r_hi = (unsigned long long)((0.5 + delta) * (double)count_s);
+        if (r_hi >= count_s) r_hi = count_s - 1;
+        if (r_lo > r_hi) r_lo = r_hi;
+        unsigned* buf = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) + stats_head_bytes(n));
+        hipLaunchKernelGGL(gram_stats_init_kernel, dim3(1), dim3(256), 0, st, ws, r_lo, r_hi, 1,
+                           (unsigned long long)stats_band_cap(n));
+        TriArgs t;
+        fill_tri_args(&t, Z, ns, d, ld * stride);  // 1. the sample's two quantile keys (three small sweeps)
+        t.st_hist = ws->hist;
+        t.st_prefix = ws->prefix;
+        for (int level = 0; level < 3; ++level) {
+            t.st_level = level;
+            hipLaunchKernelGGL(cosine_tri_dma_kernel<TRI_STATS>, dim3((unsigned)t.items), dim3(TOPK_THREADS), lds, st, t);
+            hipLaunchKernelGGL(gram_stats_pick_kernel, dim3(1), dim3(256), 0, st, ws, level, no_gate);
+        }
+        hipLaunchKernelGGL(band_begin_kernel, dim3(1), dim3(64), 0, st, ws);
+        fill_tri_args(&t, Z, n, d, ld);  // 2. the one sweep over all pairs
+        t.st_part = ws->part;
+        t.bn_ws = ws;
+        t.bn_buf = buf;
+        wgs = t.items;
+        hipLaunchKernelGGL(cosine_tri_dma_kernel<TRI_BAND>, dim3((unsigned)t.items), dim3(TOPK_THREADS), lds, st, t);
+        hipLaunchKernelGGL(band_check_kernel, dim3(1), dim3(256), 0, st, ws, m0, m1);
+        for (int level = 0; level < 3; ++level) {  // 3. the middle elements inside the buffer
+            hipLaunchKernelGGL(band_hist_kernel, dim3(1024), dim3(256), 0, st, ws, buf, level);
+            hipLaunchKernelGGL(gram_stats_pick_kernel, dim3(1), dim3(256), 0, st, ws, level, no_gate);
+        }
+        hipLaunchKernelGGL(band_resolve_kernel, dim3(1), dim3(256), 0, st, ws, m0, m1);
+        t.st_part = nullptr;  // 4. only if the band missed: the radix sweeps (the sums are in place)
+        t.bn_ws = nullptr;
+        t.bn_buf = nullptr;
+        t.st_hist = ws->hist;
+        t.st_prefix = ws->prefix;
+        t.st_gate = &ws->fallback;
+        for (int level = 0; level < 3; ++level) {
+            t.st_level = level;
+            hipLaunchKernelGGL(cosine_tri_dma_kernel<TRI_STATS>, dim3((unsigned)t.items), dim3(TOPK_THREADS), lds, st, t);
+            hipLaunchKernelGGL(gram_stats_pick_kernel, dim3(1), dim3(256), 0, st, ws, level, (const unsigned*)&ws->fallback);
+        }
+    } else if (topk_use_dma(d)) {  // LDS-DMA tile loop, the tiles on and right of the diagonal in equal stretches
+        hipLaunchKernelGGL(gram_stats_init_kernel, dim3(1), dim3(256), 0, st, ws, m0, m1, 0, 0ull);
         TriArgs t;
         fill_tri_args(&t, Z, n, d, ld);
         t.st_part = ws->part;
@@ -4071,9 +4358,10 @@ int tvbf_gram_stats_f32(const float* Z, int64_t n, int64_t d, int64_t ld, double
         for (int level = 0; level < 3; ++level) {
             t.st_level = level;
             hipLaunchKernelGGL(cosine_tri_dma_kernel<TRI_STATS>, dim3((unsigned)t.items), dim3(TOPK_THREADS), lds, st, t);
-            hipLaunchKernelGGL(gram_stats_pick_kernel, dim3(1), dim3(256), 0, st, ws, level);
+            hipLaunchKernelGGL(gram_stats_pick_kernel, dim3(1), dim3(256), 0, st, ws, level, no_gate);
         }
     } else {  // register-staged loop (d a multiple of 32 only): row block x chunks of column tiles
+        hipLaunchKernelGGL(gram_stats_init_kernel, dim3(1), dim3(256), 0, st, ws, m0, m1, 0, 0ull);
         const int chunk = gram_stats_chunk(tiles);
         const int chunks = (tiles + chunk - 1) / chunk;
         wgs = (int64_t)tiles * chunks;
@@ -4100,11 +4388,25 @@ int tvbf_gram_stats_f32(const float* Z, int64_t n, int64_t d, int64_t ld, double
         for (int level = 0; level < 3; ++level) {
             a.st_level = level;
             hipLaunchKernelGGL(cosine_tile_kernel<MODE_STATS>, dim3((unsigned)wgs), dim3(TOPK_THREADS), lds, st, a);
-            hipLaunchKernelGGL(gram_stats_pick_kernel, dim3(1), dim3(256), 0, st, ws, level);
+            hipLaunchKernelGGL(gram_stats_pick_kernel, dim3(1), dim3(256), 0, st, ws, level, no_gate);
         }
     }
     hipLaunchKernelGGL(gram_stats_final_kernel, dim3(1), dim3(256), 0, st, ws, wgs, count, out5);
     HIP_TRY(hipGetLastError());
+    return TVBF_OK;
+}
+
+int tvbf_gram_stats_inspect(const void* workspace, int64_t* out6, void* stream) {
+    if (!workspace || !out6) return fail(TVBF_E_BAD_ARG, "null pointer argument");
+    GramStatsWs head;
+    HIP_TRY(hipMemcpyAsync(&head, workspace, sizeof(head), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    out6[0] = head.fallback;
+    out6[1] = (int64_t)head.below;
+    out6[2] = (int64_t)head.eq_lo;
+    out6[3] = (int64_t)head.buffered;
+    out6[4] = (int64_t)head.eq_hi;
+    out6[5] = (int64_t)head.buf_cap;
     return TVBF_OK;
 }
 

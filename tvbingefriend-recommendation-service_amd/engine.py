@@ -408,9 +408,10 @@ def upper_tri_stats(m: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def gram_stats(z: torch.Tensor, n: int | None = None) -> torch.Tensor:
+def gram_stats(z: torch.Tensor, n: int | None = None, info: dict | None = None) -> torch.Tensor:
     """{mean, std, min, max, median} of the strict upper triangle of ``z[:n] @ z[:n].T`` (5 doubles
-    on the GPU); the matrix is never stored.  ``z`` is (rows >= n, ld) fp32 with ld % 32 == 0."""
+    on the GPU); the matrix is never stored.  ``z`` is (rows >= n, ld) fp32 with ld % 32 == 0.
+    ``info`` (tests, tuning): filled with what the call did -- synchronises."""
     _require_cuda(z, "z")
     if z.dim() != 2 or not z.is_contiguous():
         raise ValueError("z must be a contiguous 2-D tensor")
@@ -425,6 +426,14 @@ def gram_stats(z: torch.Tensor, n: int | None = None) -> torch.Tensor:
         rc = lib.tvbf_gram_stats_f32(z.data_ptr(), n, z.shape[1], z.shape[1], out.data_ptr(), ws.data_ptr(),
                                      ws_bytes, _stream_ptr())
     native.check(rc, "tvbf_gram_stats_f32")
+    if info is not None:
+        import ctypes
+
+        six = (ctypes.c_int64 * 6)()
+        with torch.cuda.device(z.device):
+            native.check(lib.tvbf_gram_stats_inspect(ws.data_ptr(), six, _stream_ptr()), "tvbf_gram_stats_inspect")
+        info.update(radix_sweeps=int(six[0]), below=int(six[1]), equal_lo=int(six[2]), buffered=int(six[3]),
+                    equal_hi=int(six[4]), capacity=int(six[5]), workspace_bytes=ws_bytes)
     return out
 
 

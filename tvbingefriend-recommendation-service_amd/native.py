@@ -51,6 +51,7 @@ SYMBOLS = (
     "tvbf_gram_f32",
     "tvbf_gram_stats_workspace_bytes",
     "tvbf_gram_stats_f32",
+    "tvbf_gram_stats_inspect",
     "tvbf_component_scores_f32",
     "tvbf_refine_min_similarity_f64",
     "tvbf_weighted_sum3_f64",
@@ -212,6 +213,8 @@ def load() -> ctypes.CDLL:
     lib.tvbf_gram_stats_workspace_bytes.argtypes = [i64]
     lib.tvbf_gram_stats_f32.restype = c.c_int
     lib.tvbf_gram_stats_f32.argtypes = [vp, i64, i64, i64, vp, vp, sz, vp]
+    lib.tvbf_gram_stats_inspect.restype = c.c_int
+    lib.tvbf_gram_stats_inspect.argtypes = [vp, c.POINTER(i64), vp]
     lib.tvbf_weighted_sum3_f64.restype = c.c_int
     lib.tvbf_weighted_sum3_f64.argtypes = [vp, vp, vp, c.c_double, c.c_double, c.c_double, vp, i64, vp]
     lib.tvbf_stats_workspace_bytes.restype = sz
