@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Random shapes through every route of the top-K sweep (run on the GPU box):
 
-    python tools/fuzz_routes.py [first_seed] [count]
+    python tools/fuzz_routes.py [first_seed] [count] [big]
 
 For every seed: a random catalogue (dense gaussian, hybrid-like, few distinct rows, one-hot rows),
 random n, d, K and threshold.  The general sweep on the LDS-DMA loop is the reference point; the
@@ -66,14 +66,15 @@ def same(a, b):
     return all(torch.equal(getattr(a, f), getattr(b, f)) for f in ("idx", "score", "count"))
 
 
-def run_seeds(first: int, count: int) -> int:
-    """0 when every route agreed for every seed (an oracle mismatch raises AssertionError)."""
+def run_seeds(first: int, count: int, big: bool = False) -> int:
+    """0 when every route agreed for every seed (an oracle mismatch raises AssertionError).
+    ``big``: catalogues of up to 20,000 shows and rows of up to 2,048 floats."""
     dev = torch.device("cuda:0")
     for seed in range(first, first + count):
         rng = np.random.default_rng(1000 + seed)
         kind = ("dense", "hybrid", "few", "onehot")[int(rng.integers(0, 4))]
-        n = int(rng.choice([130, 257, 640, 1000, 1921, 2500, 4097, 6000]))
-        d = int(rng.choice([32, 64, 96, 128, 192, 256, 320, 512]))
+        n = int(rng.choice([5000, 8200, 12000, 20000] if big else [130, 257, 640, 1000, 1921, 2500, 4097, 6000]))
+        d = int(rng.choice([64, 576, 1024, 2048] if big else [32, 64, 96, 128, 192, 256, 320, 512]))
         k = int(rng.choice([1, 2, 5, 10, 20, 30, 31, 50, 100]))
         ms = float(rng.choice([-1.0, 0.0, 0.1, 0.3]))
         print(f"seed {seed}: {kind} n={n} d={d} k={k} min={ms}", end=" ", flush=True)
@@ -109,4 +110,5 @@ def run_seeds(first: int, count: int) -> int:
 
 
 if __name__ == "__main__":
-    sys.exit(run_seeds(int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 40))
+    sys.exit(run_seeds(int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 40,
+                       big=len(sys.argv) > 3 and sys.argv[3] == "big"))
