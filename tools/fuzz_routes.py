@@ -92,6 +92,15 @@ def run_seeds(first: int, count: int, big: bool = False) -> int:
                 routes.append(("matrix", with_env({"TVBF_SYM_ROUTE": "matrix"}, lambda: engine.cosine_topk_symmetric(z, k, ms))))
             if n > 1920 and with_env({"TVBF_SYM_ROUTE": "fused"}, lambda: engine.symmetric_workspace_bytes(n, ld, k)) > 0:
                 routes.append(("fused symmetric", with_env({"TVBF_SYM_ROUTE": "fused"}, lambda: engine.cosine_topk_symmetric(z, k, ms))))
+        if ld % 64 == 0:  # every rank of a symmetric sharded job, driven in lockstep on this GPU
+            from test_gpu_symmetric import _lockstep_ranks
+            from tvbingefriend_recommendation_service_amd import sharding
+
+            world = int(rng.choice([2, 3, 4, 5, 8]))
+            stored = bool(rng.integers(0, 2))
+            if sharding.symmetric_route_fits(world, k, ld):
+                got, _flag = _lockstep_ranks(dev, z, n, world, k, ms, own_matrix=stored)
+                routes.append((f"{world} ranks{' (stored own blocks)' if stored else ''}", got))
         torch.cuda.synchronize()
         for name, got in routes:
             if not same(ref, got):
