@@ -2,7 +2,7 @@
 """Phase breakdown of the LDS-DMA kernels' k-block pair loop (needs a timing-only build made with
 -DTVBF_DIAG_TIMELINE; such a build is never shipped):
 
-    TVBF_LIB=build/libtvbf_timeline.so python tools/timeline_dma.py [n] [d] [k] [plain|symmetric]
+    TVBF_LIB=build/libtvbf_timeline.so python tools/timeline_dma.py [n] [d] [k] [plain|symmetric] [hybrid|dense]
 
 Every wavefront sums the cycle-counter time between the marks of a pair of k-blocks:
   issueA  LDS-DMA transfers and query loads of the next k-block issued
@@ -28,17 +28,23 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 k = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 sweep = sys.argv[4] if len(sys.argv) > 4 else "plain"
+data = sys.argv[5] if len(sys.argv) > 5 else "hybrid"  # or "dense": gaussian rows, threshold off
 dev = torch.device("cuda:0")
-x = torch.zeros((n, d), device=dev)
-x[:, :32] = (torch.rand((n, 32), device=dev) < 0.08).float()
-t_ = torch.randn((n, d - 64), device=dev).abs_()
-t_ *= torch.rand((n, d - 64), device=dev) < 0.03
-x[:, 32:d - 32] = t_
-del t_
-x[torch.arange(n, device=dev), d - 32 + torch.randint(0, 32, (n,), device=dev)] = 1.0
-z = engine.normalize_blocks(x, [0, 32, d - 32, d], [0.4 ** 0.5, 0.5 ** 0.5, 0.1 ** 0.5])
-del x
-run = (lambda: engine.cosine_topk(z, k, 0.1)) if sweep == "plain" else (lambda: engine.cosine_topk_symmetric(z, k, 0.1))
+if data == "dense":
+    z = engine.normalize_blocks(torch.randn((n, d), device=dev), [0, d], [1.0])
+    ms = -1.0
+else:
+    x = torch.zeros((n, d), device=dev)
+    x[:, :32] = (torch.rand((n, 32), device=dev) < 0.08).float()
+    t_ = torch.randn((n, d - 64), device=dev).abs_()
+    t_ *= torch.rand((n, d - 64), device=dev) < 0.03
+    x[:, 32:d - 32] = t_
+    del t_
+    x[torch.arange(n, device=dev), d - 32 + torch.randint(0, 32, (n,), device=dev)] = 1.0
+    z = engine.normalize_blocks(x, [0, 32, d - 32, d], [0.4 ** 0.5, 0.5 ** 0.5, 0.1 ** 0.5])
+    del x
+    ms = 0.1
+run = (lambda: engine.cosine_topk(z, k, ms)) if sweep == "plain" else (lambda: engine.cosine_topk_symmetric(z, k, ms))
 run()
 torch.cuda.synchronize()
 buf = torch.zeros((1 << 12, 4, 16), dtype=torch.int64, device=dev)
