@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void assemble_normalize_kernel(Sources src, Bl
     if (wave >= rows_per_wg || row >= n) return;  // rows are wave-private: no workgroup barrier below
     float* r = rows + (size_t)wave * ldz;
 
-    for (int64_t c = lane; c < ldz; c += 64) r[c] = 0.f;
+    for (int64_t c = 4 * lane; c < ldz; c += 256) *reinterpret_cast<float4*>(r + c) = float4{0.f, 0.f, 0.f, 0.f};
     wave_phase();
 
     for (int s = 0; s < src.ns; ++s) {
@@ -94,11 +94,23 @@ __global__ __launch_bounds__(256) void assemble_normalize_kernel(Sources src, Bl
     for (int b = 0; b < bd.nb; ++b) {
         const int c0 = bd.off[b], c1 = bd.off[b + 1];
         const unsigned width = (unsigned)(c1 - c0);
+        // a block that starts and ends on a multiple of four floats (the packing of the feature
+        // arrays) holds a lane's four floats entirely or not at all: one test instead of four
+        const bool whole4 = ((c0 | c1) & 3) == 0;
         float ss = 0.f;
         for (int base = (c0 / 256) * 256; base < c1; base += 256) {
             const int c = base + 4 * lane;
             if (c >= ldz) continue;
             const float4 v = *reinterpret_cast<const float4*>(r + c);
+            if (whole4) {
+                if ((unsigned)(c - c0) < width) {
+                    ss = fmaf(v.x, v.x, ss);
+                    ss = fmaf(v.y, v.y, ss);
+                    ss = fmaf(v.z, v.z, ss);
+                    ss = fmaf(v.w, v.w, ss);
+                }
+                continue;
+            }
             if ((unsigned)(c - c0) < width) ss = fmaf(v.x, v.x, ss);
             if ((unsigned)(c + 1 - c0) < width) ss = fmaf(v.y, v.y, ss);
             if ((unsigned)(c + 2 - c0) < width) ss = fmaf(v.z, v.z, ss);
@@ -112,6 +124,13 @@ __global__ __launch_bounds__(256) void assemble_normalize_kernel(Sources src, Bl
             const int c = base + 4 * lane;
             if (c >= ldz) continue;
             float4 v = *reinterpret_cast<const float4*>(r + c);
+            if (whole4) {
+                if ((unsigned)(c - c0) < width) {
+                    v.x *= f, v.y *= f, v.z *= f, v.w *= f;
+                    *reinterpret_cast<float4*>(r + c) = v;
+                }
+                continue;
+            }
             if ((unsigned)(c - c0) < width) v.x *= f;
             if ((unsigned)(c + 1 - c0) < width) v.y *= f;
             if ((unsigned)(c + 2 - c0) < width) v.z *= f;
