@@ -384,3 +384,31 @@ def test_session_budgets_respect_the_merge_limit(pkg, device):
     torch.cuda.synchronize()
     for f in ("idx", "score", "count"):
         assert torch.equal(getattr(top, f), getattr(full, f)), f
+
+
+def test_component_scores_of_mutual_pairs_computed_once(pkg, device, monkeypatch):
+    """When the query rows are rows of the catalogue, a pair that sits in both shows' lists is
+    computed by one wave and written to both slots: same numbers, bit for bit, as with every pair
+    computed on its own -- for the whole catalogue and for a shard of its rows."""
+    import torch
+
+    from tvbingefriend_recommendation_service_amd import engine
+
+    n, k = 3000, 20
+    g, t, p, ty, la = hybrid_like_blocks(n, seed=31, d_genre=16, d_text=208)
+    x = np.ascontiguousarray(np.hstack([g, t, p, ty, la]), dtype=np.float32)
+    offsets = [0, 16, 224, x.shape[1]]
+    scales = [float(np.sqrt(w)) for w in (0.4, 0.5, 0.1)]
+    z = engine.normalize_blocks(torch.from_numpy(x).to(device), offsets, scales)
+    top = engine.cosine_topk(z, k, 0.05)
+    idx = top.idx
+    lists_of_neighbours = idx[idx.long().clamp(min=0)]  # (n, k, k)
+    mutual = (lists_of_neighbours == torch.arange(n, device=device).view(n, 1, 1)).any(dim=2) & (idx >= 0)
+    assert 0.2 * n * k < int(mutual.sum()) < n * k  # the case is there, and so is its opposite
+    once = engine.component_scores(z, offsets, scales, idx)
+    r0, nq = 1111, 700
+    shard = engine.component_scores(z, offsets, scales, idx[r0:r0 + nq].contiguous(), q_row0=r0)
+    monkeypatch.setenv("TVBF_K5_NO_MUTUAL", "1")
+    each = engine.component_scores(z, offsets, scales, idx)
+    torch.cuda.synchronize()
+    assert torch.equal(once, each) and torch.equal(shard, each[r0:r0 + nq])
