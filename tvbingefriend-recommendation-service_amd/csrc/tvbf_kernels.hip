@@ -6,12 +6,16 @@
 //   cosine_topk_dma_kernel    the same fused top-K with the LDS-DMA tile loop (d % 64 == 0), its work
 //                             cut into equal stretches; symmetric variants feed the lists of the
 //                             column shows too, so that every pair of shows is computed once
+//   cosine_tri_dma_kernel     the tiles on and above the diagonal once, LDS-DMA loop: stored as an n x n
+//                             matrix (small catalogues; matrix_rows_topk_kernel selects from it) or
+//                             folded into statistics (radix histograms, or one sweep that keeps the
+//                             scores of a band around the median)
 //   col_reduce_kernel         column-side buffers -> one more partial list per show
 //   bound_merge_kernel        row lists + column buffer of a show -> its bound key (between symmetric sweeps)
 //   topk_finalize_kernel      merge of the partial lists of a row
 //   component_scores_kernel   per-block cosines of the kept pairs
 //   query_*_kernel            a few query vectors against the whole catalogue (HBM-bound)
-//   gram_stats_*_kernel       radix-select bookkeeping of the statistics mode
+//   gram_stats_* / band_*     bookkeeping of the statistics mode (rank look-up, band check, selection in the buffer)
 //
 // The C ABI is declared in include/tvbf.h.  No torch types, no device allocation.
 
@@ -1037,7 +1041,7 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tile_kernel(TopkArgs a
 // --------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void* global_cvoid_t;
-constexpr int DMA_SLOTS = 8;  // scores a lane can queue per collect pass
+constexpr int DMA_SLOTS = 8;  // scores a lane can queue in the wave's scratch before the pop loop hands them on
 
 // One LDS-DMA transfer, 16 bytes per lane: global memory at `base + voff` (base uniform) to the
 // LDS at `lds_dst` (uniform) + 16 * lane.  Issued as buffer_load_dwordx4 ... lds, NOT as
