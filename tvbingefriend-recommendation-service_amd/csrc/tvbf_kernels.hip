@@ -2639,22 +2639,24 @@ __global__ __launch_bounds__(256) void component_scores_kernel(const float* __re
         if (lane < bd.nb) o[lane] = 0.f;
         return;
     }
-    float* o2 = nullptr;  // the neighbour's slot for this show, when the pair is mutual
-    if (q_row0 >= 0) {
-        const int64_t gi = q_row0 + row, jr = (int64_t)j - q_row0;
-        if (jr >= 0 && jr < nq && (int64_t)j != gi) {
-            const int32_t* other = idx + jr * k;
-            int pos = -1;
-            for (int base = 0; base < k && pos < 0; base += 64) {
-                const u64 hit = __ballot(base + lane < k && other[base + lane] == (int32_t)gi);
-                if (hit) pos = base + (int)__builtin_ctzll(hit);
-            }
-            if (pos >= 0) {
-                if ((int64_t)j < gi) return;  // the neighbour's wave writes both
-                o2 = out + (jr * k + pos) * bd.nb;
-            }
+    // Position of this show in its neighbour's list (-1: not there, or the query rows are no rows of
+    // zall).  The wave of the higher show index looks first and returns if the pair is mutual; the
+    // wave of the lower index computes in any case, so its look-up is in flight together with its
+    // row loads and only tells it the second slot to write.
+    const int64_t gi = q_row0 + row, jr = (int64_t)j - q_row0;
+    const bool partner_here = q_row0 >= 0 && jr >= 0 && jr < nq && (int64_t)j != gi;
+    auto find_me = [&]() {
+        const int32_t* other = idx + jr * k;
+        int pos = -1;
+        for (int base = 0; base < k && pos < 0; base += 64) {
+            const u64 hit = __ballot(base + lane < k && other[base + lane] == (int32_t)gi);
+            if (hit) pos = base + (int)__builtin_ctzll(hit);
         }
-    }
+        return pos;
+    };
+    if (partner_here && (int64_t)j < gi && find_me() >= 0) return;  // the neighbour's wave writes both slots
+    const int pos2 = (partner_here && gi < (int64_t)j) ? find_me() : -1;
+    float* const o2 = pos2 >= 0 ? out + (jr * k + pos2) * bd.nb : nullptr;
     const float* x = zq + row * ld;
     const float* y = zall + (int64_t)j * ld;
     for (int b = 0; b < bd.nb; ++b) {
