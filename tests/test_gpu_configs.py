@@ -145,6 +145,15 @@ def test_config5_one_rank_of_eight_at_1m_x_2048(pkg, device):
     assert not np.any(idx == (me.row0 + np.arange(me.rows))[:, None])
     rows = np.sort(np.random.default_rng(5).choice(me.rows, size=24, replace=False))
     del z_all
+    # every row of the rank against float64 scores computed on the GPU by torch (the chunks regenerated)
+    z64_all = torch.empty((n, d), dtype=torch.float64, device=device)
+    for c0 in range(0, n, CHUNK):
+        z64_all[c0:c0 + CHUNK] = _z_float64(torch, _hybrid_chunk(torch, device, CHUNK, d, 50001 + c0 // CHUNK), offsets, weights)
+    f_ranks, f_exact, f_err = _compare_with_float64_rows(torch, device, z64_all[me.row0:me.row0 + me.rows], z64_all, me.row0,
+                                                        plain, k, ms, 250)
+    del z64_all
+    assert f_ranks > 0.99 * me.rows * k and f_exact >= 0.8 * f_ranks and f_err <= 1e-6, (f_ranks, f_exact, f_err)
+    print(f"config 5, rank {rank}: {f_ranks} ranks against float64 on the GPU, {f_exact} by index, max score error {f_err:.2e}")
     def z64_chunk(c0):
         xh = _hybrid_chunk(torch, device, CHUNK, d, 50001 + c0 // CHUNK).cpu().numpy().astype(np.float64)
         return so.build_z([xh[:, offsets[b]:offsets[b + 1]] for b in range(3)], weights)
@@ -166,39 +175,19 @@ def test_config5_one_rank_of_eight_at_1m_x_2048(pkg, device):
     print(f"config 5, rank {rank} of {world}: {stats}, executed share {executed:.3f}")
 
 
-def test_config3_100k_x_1024_every_row_against_float64(pkg, device):
-    """BASELINE config #3 at full size, EVERY row: the symmetric call's lists against float64 scores
-    of all 10^10 pairs, computed on the GPU by torch (rocBLAS dgemm -- a code path that shares
-    nothing with the kernels under test) from rows normalised in float64.  Same bar as
-    tests/parity.py: counts inside the threshold band, every reported score and every rank's score
-    within 1e-6, indices equal at every rank more than 2e-6 from both neighbours."""
-    import torch
-
-    from tvbingefriend_recommendation_service_amd import engine
-
-    if torch.cuda.get_device_properties(device).total_memory < 40 * 2**30:
-        pytest.skip("needs about 8 GB of device memory")
-    n, d, k, ms, tol, gap = 100_000, 1024, 20, 0.1, 1e-6, 2e-6
-    offsets, weights = [0, 32, d - 32, d], [0.4, 0.5, 0.1]
-    x = _hybrid_chunk(torch, device, n, d, 30003)
-    z = engine.normalize_blocks(x, offsets, [float(np.sqrt(w)) for w in weights])
-    top = engine.catalogue_topk(z, k, ms)
-    assert engine.symmetric_workspace_bytes(n, z.shape[1], k) > 0  # the symmetric route took it
-    z64 = torch.zeros((n, d), dtype=torch.float64, device=device)
-    for b, w in enumerate(weights):  # sklearn's normalize: a zero row stays zero (similarity_computer.py:41-60)
-        xb = x[:, offsets[b]:offsets[b + 1]].double()
-        nrm = xb.norm(dim=1, keepdim=True)
-        nrm[nrm == 0] = 1.0
-        z64[:, offsets[b]:offsets[b + 1]] = float(np.sqrt(w)) * xb / nrm
-    del x
-    rows_per_chunk = 2500
+def _compare_with_float64_rows(torch, device, z64_q, z64_all, row0, top, k, ms, rows_per_chunk, tol=1e-6, gap=2e-6):
+    """The lists of query rows row0.. (global numbering; ``top`` holds one row per query) against
+    float64 scores z64_q @ z64_all.T computed by torch on the GPU.  Returns (ranks compared, ranks
+    compared by index, largest score error); asserts the bar of tests/parity.py with a 1e-6 score
+    tolerance."""
+    nq, n = z64_q.shape[0], z64_all.shape[0]
     ar_k = torch.arange(k, device=device)
     ranks = exact = 0
     max_err = 0.0
-    for c0 in range(0, n, rows_per_chunk):
-        r = min(rows_per_chunk, n - c0)
-        h = z64[c0:c0 + r] @ z64.T
-        h[torch.arange(r, device=device), c0 + torch.arange(r, device=device)] = -float("inf")
+    for c0 in range(0, nq, rows_per_chunk):
+        r = min(rows_per_chunk, nq - c0)
+        h = z64_q[c0:c0 + r] @ z64_all.T
+        h[torch.arange(r, device=device), row0 + c0 + torch.arange(r, device=device)] = -float("inf")
         vals, inds = torch.topk(h, k + 1, dim=1)
         cnt = top.count[c0:c0 + r].long()
         lo = (h >= ms + 1e-5).sum(1).clamp(max=k)
@@ -219,5 +208,41 @@ def test_config3_100k_x_1024_every_row_against_float64(pkg, device):
         exact += int(clear.sum())
         max_err = max(max_err, float(err.max()))
         del h, vals, inds, at
+    return ranks, exact, max_err
+
+
+def _z_float64(torch, x, offsets, weights):
+    """Block-wise L2 normalisation and weighting in float64 (sklearn's normalize: a zero row stays
+    zero -- ml/similarity_computer.py:41-60)."""
+    z64 = torch.zeros(x.shape, dtype=torch.float64, device=x.device)
+    for b, w in enumerate(weights):
+        xb = x[:, offsets[b]:offsets[b + 1]].double()
+        nrm = xb.norm(dim=1, keepdim=True)
+        nrm[nrm == 0] = 1.0
+        z64[:, offsets[b]:offsets[b + 1]] = float(np.sqrt(w)) * xb / nrm
+    return z64
+
+
+def test_config3_100k_x_1024_every_row_against_float64(pkg, device):
+    """BASELINE config #3 at full size, EVERY row: the symmetric call's lists against float64 scores
+    of all 10^10 pairs, computed on the GPU by torch (rocBLAS dgemm -- a code path that shares
+    nothing with the kernels under test) from rows normalised in float64.  Same bar as
+    tests/parity.py: counts inside the threshold band, every reported score and every rank's score
+    within 1e-6, indices equal at every rank more than 2e-6 from both neighbours."""
+    import torch
+
+    from tvbingefriend_recommendation_service_amd import engine
+
+    if torch.cuda.get_device_properties(device).total_memory < 40 * 2**30:
+        pytest.skip("needs about 8 GB of device memory")
+    n, d, k, ms = 100_000, 1024, 20, 0.1
+    offsets, weights = [0, 32, d - 32, d], [0.4, 0.5, 0.1]
+    x = _hybrid_chunk(torch, device, n, d, 30003)
+    z = engine.normalize_blocks(x, offsets, [float(np.sqrt(w)) for w in weights])
+    top = engine.catalogue_topk(z, k, ms)
+    assert engine.symmetric_workspace_bytes(n, z.shape[1], k) > 0  # the symmetric route took it
+    z64 = _z_float64(torch, x, offsets, weights)
+    del x
+    ranks, exact, max_err = _compare_with_float64_rows(torch, device, z64, z64, 0, top, k, ms, 2500)
     assert ranks > 0.99 * n * k and exact >= 0.85 * ranks, (ranks, exact)  # measured 89.5 %: hybrid rows tie often (equal genre / metadata parts)
     print(f"config 3: {ranks} ranks compared, {exact} by index, max score error {max_err:.2e}")
