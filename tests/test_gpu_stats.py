@@ -165,3 +165,57 @@ def test_band_route_is_the_default_for_large_catalogues(pkg, device, monkeypatch
     monkeypatch.setenv("TVBF_STATS_ROUTE", "radix")
     radix = engine.gram_stats(z).cpu().numpy()
     assert np.array_equal(radix, band), (radix, band, info)
+
+
+def test_band_route_at_100k_verified_by_counting(pkg, device):
+    """N = 100,000: the one-sweep statistics checked against the kernel's own fp32 scores, produced
+    tile by tile through the dense-matrix entry point and folded with torch: the median is the mean
+    of two adjacent scores with exactly half of the 4,999,950,000 scores below it, min and max are
+    exact, mean and std agree with float64 sums."""
+    import torch
+
+    from tvbingefriend_recommendation_service_amd import engine
+
+    if torch.cuda.get_device_properties(device).total_memory < 40 * 2**30:
+        pytest.skip("needs about 10 GB of device memory")
+    n, d = 100_000, 256
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1234)
+    z = engine.normalize_blocks(torch.randn((n, d), generator=gen, device=device), [0, d], [1.0])
+    info = {}
+    got = engine.gram_stats(z, info=info).cpu().numpy()
+    assert info["radix_sweeps"] == 0 and info["buffered"] <= info["capacity"], info
+    count = n * (n - 1) // 2
+    med = float(got[4])
+    below = above = 0
+    lower, upper = -np.inf, np.inf
+    s = sq = 0.0
+    mn, mx = np.inf, -np.inf
+    cols = torch.arange(n, device=device)
+    rows_per_chunk = 4000
+    for r0 in range(0, n, rows_per_chunk):
+        r = min(rows_per_chunk, n - r0)
+        sc = engine.gram(z, q_row0=r0, nq=r)
+        v = sc[cols[None, :] > (r0 + torch.arange(r, device=device))[:, None]].double()
+        del sc
+        if v.numel() == 0:
+            continue
+        below += int((v < med).sum())
+        above += int((v > med).sum())
+        le, ge = v[v <= med], v[v >= med]
+        if le.numel():
+            lower = max(lower, float(le.max()))
+        if ge.numel():
+            upper = min(upper, float(ge.min()))
+        s += float(v.sum())
+        sq += float((v * v).sum())
+        mn, mx = min(mn, float(v.min())), max(mx, float(v.max()))
+        del v, le, ge
+    assert count % 2 == 0 and lower <= med <= upper
+    if below == count // 2:  # the two middle scores differ: the median lies between them
+        assert above == count // 2 and med == 0.5 * (lower + upper), (below, above, lower, med, upper)
+    else:  # a tie across the middle
+        assert lower == med == upper and below < count // 2 and above < count // 2, (below, above, lower, med, upper)
+    assert got[2] == mn and got[3] == mx
+    mean = s / count
+    assert abs(got[0] - mean) <= 1e-11 and abs(got[1] - np.sqrt(sq / count - mean * mean)) <= 1e-10, (got, mean)
