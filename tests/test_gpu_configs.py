@@ -5,6 +5,8 @@
     against the float64 oracle, and the plain and symmetric sweeps against each other bit for bit;
   * N = 100,000 x D = 1024 hybrid-like, K = 20, min 0.1 (the benchmark's own shape): every row of the
     symmetric call against float64 scores of all pairs computed on the GPU by torch;
+  * the same catalogue as the eight ranks of the row-sharded job (BASELINE config #4), driven in
+    lockstep on one GPU: symmetric and plain sharded routes against the single-GPU lists, bit for bit;
   * N = 1,000,000 x D = 2048 hybrid-like, K = 50, min 0.1, 8 ranks: one rank's share with the whole
     normalised matrix resident -- its rows through the plain sharded route and through the symmetric
     sharded route (the ranks that feed its rows driven in lockstep on this one GPU), bit for bit,
@@ -254,3 +256,37 @@ def test_config3_100k_x_1024_every_row_against_float64(pkg, device, k, ms, kind)
     ranks, exact, max_err = _compare_with_float64_rows(torch, device, z64, z64, 0, top, k, ms, 2500)
     assert ranks > 0.99 * n * k and exact >= 0.85 * ranks, (ranks, exact)  # K=20 hybrid: 89.5 % (equal genre / metadata parts tie often)
     print(f"config 3, K={k} {kind}: {ranks} ranks compared, {exact} by index, max score error {max_err:.2e}")
+
+
+def test_config4_eight_ranks_at_100k_x_1024(pkg, device):
+    """BASELINE config #4 at full size: the eight ranks of the row-sharded job, driven in lockstep on
+    one GPU (collectives replaced by indexing) -- symmetric sharded route with the own blocks through
+    the stored-matrix route, as bench.py runs it, and the plain sharded route (own columns, then the
+    gathered rest) -- give, rank by rank, the single-GPU lists bit for bit (which
+    test_config3_100k_x_1024_every_row_against_float64 holds against float64)."""
+    import torch
+
+    from test_gpu_symmetric import _lockstep_ranks
+    from tvbingefriend_recommendation_service_amd import engine, sharding
+
+    if torch.cuda.get_device_properties(device).total_memory < 64 * 2**30:
+        pytest.skip("needs about 20 GB of device memory")
+    n, d, k, ms, world = 100_000, 1024, 20, 0.1, 8
+    offsets, weights = [0, 32, d - 32, d], [0.4, 0.5, 0.1]
+    z = engine.normalize_blocks(_hybrid_chunk(torch, device, n, d, 30003), offsets, [float(np.sqrt(w)) for w in weights])
+    want = engine.catalogue_topk(z, k, ms)
+    got, flag = _lockstep_ranks(device, z, n, world, k, ms, own_matrix=True)
+    assert flag == 0
+    for f in ("idx", "score", "count"):
+        assert torch.equal(getattr(got, f), getattr(want, f)), f"symmetric sharded route: {f}"
+    del got
+    for rank in range(world):  # plain sharded route, rank by rank
+        sh = sharding.shard_bounds(n, world, rank)
+        own, after, before = sharding.column_pieces(sh)
+        zq = z[sh.row0:sh.row0 + sh.rows]
+        ses = engine.TopkSession(zq, sh.rows, sh.row0, k, ms)
+        ses.accumulate((zq, own[1], own[0]))
+        ses.accumulate((z[after[0]:], after[1], after[0]), (z, before[1], before[0]))
+        part = ses.finish()
+        for f in ("idx", "score", "count"):
+            assert torch.equal(getattr(part, f)[: sh.rows], getattr(want, f)[sh.row0:sh.row0 + sh.rows]), f"plain sharded route, rank {rank}: {f}"
