@@ -186,7 +186,8 @@ def end_to_end(x_host, offsets, scales, k, min_similarity, dev):
         "pairs_kept": int(len(table["show_id"])),
         "record_dicts_s": d[4], "shows_with_records": len(records),
         "note": "single pass, cold allocations included; record_dicts_s = the reference's dict[int, list[dict]] form "
-                "built from the same arrays (host Python), not part of host_features_to_host_table_s",
+                "built from the same arrays (csrc/_tvbf_records.so when it is built, else a Python loop), not part of "
+                "host_features_to_host_table_s",
     }
 
 

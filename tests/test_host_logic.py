@@ -504,3 +504,44 @@ def test_symmetric_partition_covers_every_pair_once(pkg, world, n):
     work = covered.sum(axis=1)
     if n >= 1000 and world > 1:
         assert work.max() <= 1.1 * work.mean() + 2 * 128 * max(s.rows for s in shards)
+
+
+def test_record_dicts_built_in_c_equal_the_python_loop(pkg):
+    """csrc/_tvbf_records.so builds the reference's dict[int, list[dict]] form of a result
+    (populate_database.py:210-221); it must return exactly what the Python loop returns -- ids as
+    a list or as an array, whole result or a slice of rows, shows without neighbours left out --
+    and step aside for ids that are not integers."""
+    from tvbingefriend_recommendation_service_amd import native
+    from tvbingefriend_recommendation_service_amd.ml.similarity_computer import TopKResult
+    from tvbingefriend_recommendation_service_amd.scripts import populate_database as pd_
+
+    if native.build_records_ext() is None:
+        pytest.skip("no C compiler or no Python headers here")
+    assert pd_._load_records_ext(), "the extension was built but does not load"
+    rng = np.random.default_rng(3)
+    n, k = 300, 7
+    count = rng.integers(0, k + 1, n).astype(np.int32)
+    idx = np.full((n, k), -1, dtype=np.int32)
+    score = np.zeros((n, k), dtype=np.float32)
+    comp = np.zeros((n, k, 3), dtype=np.float64)
+    for r in range(n):
+        c = count[r]
+        idx[r, :c] = rng.choice(n, size=c, replace=False)
+        score[r, :c] = np.sort(rng.random(c).astype(np.float32))[::-1]
+        comp[r, :c] = rng.random((c, 3))
+    res = TopKResult(idx, score, count, comp)
+    ids = [10_000_000_000 + 3 * i for i in range(n)]  # beyond 32 bits
+    for show_ids in (ids, np.asarray(ids)):
+        for start, stop in ((0, n), (17, 203), (5, 5)):
+            want = pd_.neighbour_records(res, show_ids, start, stop, use_ext=False)
+            got = pd_.neighbour_records(res, show_ids, start, stop)
+            assert got == want and list(got) == list(want)
+            for key, items in got.items():
+                assert type(key) is int and all(list(d) == list(w) for d, w in zip(items, want[key]))
+                assert all(type(v) is (int if name == "similar_show_id" else float) for d in items for name, v in d.items())
+    names = [f"show-{i}" for i in range(n)]  # not integers: the Python loop
+    assert pd_.neighbour_records(res, names, 0, n) == pd_.neighbour_records(res, names, 0, n, use_ext=False)
+    bad = TopKResult(idx.copy(), score, count, comp)
+    bad.idx[np.nonzero(count)[0][0], 0] = n + 5
+    with pytest.raises(ValueError):
+        pd_.neighbour_records(bad, ids, 0, n)

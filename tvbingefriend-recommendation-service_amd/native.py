@@ -116,6 +116,32 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     return LIB_PATH
 
 
+RECORDS_EXT_PATH = CSRC / "_tvbf_records.so"  # CPython extension: record dicts of a top-K result (host formatting)
+
+
+def build_records_ext(force: bool = False):
+    """Compile csrc/tvbf_records.c with the host compiler into csrc/_tvbf_records.so.  Returns the
+    path, or None when the interpreter's headers or a C compiler are missing (the Python loop of
+    scripts.populate_database.neighbour_records then does the same work)."""
+    import shutil
+    import sysconfig
+
+    src = CSRC / "tvbf_records.c"
+    inc = sysconfig.get_paths().get("include")
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if not cc or not inc or not (Path(inc) / "Python.h").exists():
+        return None
+    if not force and RECORDS_EXT_PATH.exists() and RECORDS_EXT_PATH.stat().st_mtime >= src.stat().st_mtime:
+        return RECORDS_EXT_PATH
+    tmp = RECORDS_EXT_PATH.with_suffix(".so.tmp")
+    res = subprocess.run([cc, "-O2", "-fPIC", "-shared", "-Wall", f"-I{inc}", "-o", str(tmp), str(src)],
+                         capture_output=True, text=True)
+    if res.returncode != 0:
+        raise NativeLibraryError(f"{cc} failed on {src}:\n{res.stderr}")
+    os.replace(tmp, RECORDS_EXT_PATH)
+    return RECORDS_EXT_PATH
+
+
 _lib = None
 
 
