@@ -400,3 +400,58 @@ def test_rccl_route_one_rank_group(pkg, device):
         assert float(flag.item()) == 3.0
     finally:
         dist.destroy_process_group()
+
+
+def test_whole_step_can_be_captured_in_a_graph(pkg, device, monkeypatch):
+    """K1, the catalogue top-K, K5, the one-sweep statistics (with its gated fall-back launches) and a
+    batch of single-show queries captured as ONE HIP graph: the library clears memory with kernels
+    and synchronises nothing, so every replay -- on new input data, with unrelated eager work and
+    synchronisations in between -- must reproduce the eager results bit for bit."""
+    import torch
+
+    from tvbingefriend_recommendation_service_amd import engine
+
+    n, d, k, ms = 3000, 256, 20, 0.05
+    offsets, scales = [0, 32, 224, 256], [float(np.sqrt(w)) for w in (0.4, 0.5, 0.1)]
+    monkeypatch.setenv("TVBF_STATS_ROUTE", "band")
+    gen = torch.Generator(device=device)
+
+    def data(seed):
+        gen.manual_seed(seed)
+        x = torch.randn((n, d), generator=gen, device=device).abs_()
+        x *= torch.rand((n, d), generator=gen, device=device) < 0.2
+        return x
+
+    x_buf = data(0)
+    z_buf = torch.empty((n, d), device=device)
+
+    def step():
+        z = engine.normalize_blocks(x_buf, offsets, scales, out=z_buf)
+        top = engine.catalogue_topk(z, k, ms)
+        comp = engine.component_scores(z, offsets, scales, top.idx)
+        stats = engine.gram_stats(z)
+        q = engine.query_topk(z[:5], z, k, ms, self_index=[0, 1, 2, 3, 4])
+        return top, comp, stats, q
+
+    def flat(res):
+        top, comp, stats, q = res
+        return [top.idx, top.score, top.count, comp, stats, q.idx, q.score, q.count]
+
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        step()  # first call outside the capture (kernel attributes, library init)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        captured = flat(step())
+    for seed in (11, 12, 13):
+        x_buf.copy_(data(seed))
+        want = [t.clone() for t in flat(step())]  # eager, same input buffer
+        for t in captured:
+            t.zero_()
+        _ = torch.randn((128, 128), device=device) @ torch.randn((128, 128), device=device)
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        for i, (a, b) in enumerate(zip(captured, want)):
+            assert torch.equal(a, b), f"replay with seed {seed}: output {i} differs"
