@@ -455,3 +455,49 @@ def test_whole_step_can_be_captured_in_a_graph(pkg, device, monkeypatch):
         torch.cuda.synchronize()
         for i, (a, b) in enumerate(zip(captured, want)):
             assert torch.equal(a, b), f"replay with seed {seed}: output {i} differs"
+
+
+def test_concurrent_calls_from_two_threads_on_two_streams(pkg, device):
+    """The library keeps no state between calls (the static-scratch entry point aside): two host
+    threads, each on its own stream with its own workspace and catalogue, interleave symmetric and
+    plain calls and statistics -- every result equals the one computed alone."""
+    import threading
+
+    import torch
+
+    from tvbingefriend_recommendation_service_amd import engine
+
+    k = 20
+    gen = torch.Generator(device=device)
+    cats = []
+    for seed, n, d in ((1, 5000, 128), (2, 3300, 256)):
+        gen.manual_seed(seed)
+        z = engine.normalize_blocks(torch.randn((n, d), generator=gen, device=device), [0, d], [1.0])
+        cats.append((z, engine.catalogue_topk(z, k, -1.0), engine.gram_stats(z)))
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(which):
+        try:
+            z, want, want_stats = cats[which]
+            stream = torch.cuda.Stream(device=device)
+            with torch.cuda.stream(stream):
+                for rep in range(6):
+                    got = engine.catalogue_topk(z, k, -1.0) if rep % 2 == 0 else engine.cosine_topk(z, k, -1.0)
+                    st = engine.gram_stats(z)
+                    stream.synchronize()
+                    for f in ("idx", "score", "count"):
+                        if not torch.equal(getattr(got, f), getattr(want, f)):
+                            errors.append(f"thread {which} rep {rep}: {f} differs")
+                    if not torch.equal(st, want_stats):
+                        errors.append(f"thread {which} rep {rep}: statistics differ")
+        except Exception as e:  # noqa: BLE001
+            errors.append(f"thread {which}: {e!r}")
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads), "a worker did not finish"
+    assert not errors, errors
