@@ -11,7 +11,12 @@ Every wavefront sums the cycle-counter time between the marks of a pair of k-blo
   issueB / mfmaB / barB   the same for the second k-block
   epi     epilogue (last pair of a tile only)
   top     per-tile work before the pair loop
-With the symmetric sweep the half sweep is the launch that is recorded last in the buffer."""
+With the symmetric sweep the half sweep is the launch that is recorded last in the buffer.
+
+A build with -DTVBF_DIAG_TOPSPLIT on top splits `top` of a sweep with a column side: the column
+bounds of the tile are booked as issueA, the drain of the column queue as barA, the barrier behind
+it as barB and a change of row block as issueB (compare with a run of the plain timeline build);
+the three row-side counters then read: cycles inside bound refreshes, drains, refreshes."""
 import os
 import sys
 import time

@@ -1130,40 +1130,33 @@ __device__ static inline unsigned col_append(const TopkArgs& a, unsigned rowg, u
 // shows of an ordinary catalogue do), and then whenever it has grown by another col_window
 // entries (64, 128 or 256: the smallest that holds 2 K keys -- every window cuts the share of
 // ties that still pass to about K / window of what it was, so small windows converge in far
-// fewer entries), the wave that appended the last of them ranks that window (the entries already visible; buffers start zeroed and 0 is
-// no key) and raises the show's bound key to the window's K-th best: the K-th best of any set of
-// real candidates is a valid lower bound.
-__device__ static inline void col_refresh_bound(const TopkArgs& a, unsigned rowg, unsigned end, u64* scr, int lane) {
+// fewer entries), the wave that appended the last of them selects the K-th best key of that window
+// (of the entries already visible; buffers start zeroed and 0 is no key) and raises the show's
+// bound key to it: the K-th best of any set of real candidates is a valid lower bound.
+__device__ static inline void col_refresh_bound(const TopkArgs& a, unsigned rowg, unsigned end, int lane) {
     // the first window is the first COL_WINDOW_MAX entries, the later ones col_window entries each
     const unsigned window = end == COL_WINDOW_MAX ? COL_WINDOW_MAX : a.col_window;
     const u64* src = a.col_buf + (int64_t)rowg * a.col_cap + (end - window);
     const int per_lane = (int)window / 64;  // 1, 2 or 4 keys per lane
     u64 my[4];
-    int rk[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        my[u] = u < per_lane ? __hip_atomic_load(src + lane + 64 * u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-        if (u < per_lane) scr[lane + 64 * u] = my[u];
-        rk[u] = 0;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-#pragma nounroll
-    for (int i = 0; i < (int)window; i += 4) {
-        u64 o[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) o[t] = scr[i + t];  // same address in every lane: LDS broadcast
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) rk[u] += o[t] > my[u] ? 1 : 0;
-    }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-        if (my[u] != 0ull && rk[u] == a.k - 1)
-            atomicMax(reinterpret_cast<unsigned long long*>(a.col_bound + rowg), (unsigned long long)my[u]);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+        my[u] = u < per_lane ? __hip_atomic_load(src + lane + 64 * u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    // The window's K-th largest key, built bit by bit from the top: the largest t that at least K
+    // keys reach.  64 steps of four compares and four wave-wide counts, all control flow uniform --
+    // a fifth of the instructions of ranking every key against every other, and nothing goes
+    // through the LDS.  Fewer than K real keys in the window: t stays 0, the bound stays as it is.
+    u64 kth = 0ull;
+#pragma nounroll
+    for (int b = 63; b >= 0; --b) {
+        const u64 t = kth | (1ull << b);
+        int reach = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) reach += __builtin_popcountll(__ballot(my[u] >= t));
+        if (reach >= a.k) kth = t;
+    }
+    if (kth != 0ull && lane == 0)
+        atomicMax(reinterpret_cast<unsigned long long*>(a.col_bound + rowg), (unsigned long long)kth);
 }
 
 // whether the entry appended at position p completes a window of its show's buffer
@@ -1174,7 +1167,7 @@ __device__ static inline bool col_window_ends(const TopkArgs& a, unsigned p) {
 // Drain of the workgroup's queue: every thread appends its share; waves then refresh the bounds
 // of the shows whose buffers completed a window.
 __device__ static inline void col_drain(const TopkArgs& a, const unsigned* lrowg, const u64* lkey, unsigned count,
-                                        int tid, int lane, u64* scr) {
+                                        int tid, int lane, unsigned long long* n_refresh = nullptr) {
     for (unsigned base = 0; base < count; base += TOPK_THREADS) {  // uniform trip count
         const unsigned i = base + tid;
         unsigned rowg = 0u, p = 0u;
@@ -1185,11 +1178,14 @@ __device__ static inline void col_drain(const TopkArgs& a, const unsigned* lrowg
             crossed = col_window_ends(a, p);
         }
         u64 todo = __ballot(crossed);
+        unsigned long long t0 = 0;
+        if (n_refresh) n_refresh[0] += __builtin_popcountll(todo), t0 = __builtin_readcyclecounter();
         while (todo) {
             const int l = (int)__builtin_ctzll(todo);
             todo &= todo - 1ull;
-            col_refresh_bound(a, __shfl(rowg, l, 64), __shfl(p, l, 64) + 1u, scr, lane);
+            col_refresh_bound(a, __shfl(rowg, l, 64), __shfl(p, l, 64) + 1u, lane);
         }
+        if (n_refresh) n_refresh[1] += __builtin_readcyclecounter() - t0;
     }
 }
 
@@ -1436,6 +1432,9 @@ __global__ __launch_bounds__(TOPK_THREADS, TVBF_DMA_WGS) void cosine_topk_dma_ke
     dma_tile(0, tileC0);
     load_q(0, qreg[0]);
     __syncthreads();  // lists initialised, first k-block in place
+#ifdef TVBF_DIAG_TOPSPLIT  // timing-only build: segment change booked as issueB, column-side tile set-up as issueA
+    DL_MARK(3);
+#endif
 
     // k-blocks go in pairs (the host guarantees an even number per tile): A reads buffer 0 / set 0
     // and fetches into buffer 1 / set 1, B the other way round.  A barrier ends every k-block: by
@@ -1444,6 +1443,9 @@ __global__ __launch_bounds__(TOPK_THREADS, TVBF_DMA_WGS) void cosine_topk_dma_ke
     for (int ct = tile_begin; ct < tile_end; ++ct) {
         unsigned gb_bits = 0u;
         if (my_gb) gb_bits = __hip_atomic_load(my_gb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef TVBF_DIAG_TOPSPLIT
+        DL_MARK(7);
+#endif
         if (COLSIDE) {
             // the barrier that ended the previous tile also completed the loads of set_tile; the
             // epilogue that reads cbound and appends to the queue is many barriers away
@@ -1456,14 +1458,33 @@ __global__ __launch_bounds__(TOPK_THREADS, TVBF_DMA_WGS) void cosine_topk_dma_ke
                 cblo[tid] = (uint32_t)cb_key;
             }
             unsigned queued_cols = *lcnt;
+#ifdef TVBF_DIAG_TOPSPLIT
+            queued_cols = __builtin_amdgcn_readfirstlane(queued_cols);
+            DL_MARK(0);  // bounds of the tile's column shows in place
+#endif
             if (queued_cols >= (unsigned)a.col_drain) {  // uniform: drain the queue into the shows' buffers
                 if (queued_cols > (unsigned)a.col_lds) queued_cols = (unsigned)a.col_lds;
-                col_drain(a, lrowg, lkey, queued_cols, tid, lane, reinterpret_cast<u64*>(scratch));
+#ifdef TVBF_DIAG_TOPSPLIT  // counters of the column side instead of the row side's
+                ++dl_pops;
+                {
+                    unsigned long long rf[2] = {0, 0};  // refreshes, cycles in them
+                    col_drain(a, lrowg, lkey, queued_cols, tid, lane, rf);
+                    dl_compact += rf[0];
+                    dl_cand += rf[1];
+                }
+                DL_MARK(2);  // drain booked as barA
+#else
+                col_drain(a, lrowg, lkey, queued_cols, tid, lane);
+#endif
                 __syncthreads();
                 if (tid == 0) *lcnt = 0u;
             }
         }
+#ifdef TVBF_DIAG_TOPSPLIT
+        DL_MARK(6);  // barrier behind the drain booked as barB
+#else
         DL_MARK(7);
+#endif
 #pragma nounroll
         for (int kb = 0; kb < nkb; kb += 2) {
             __builtin_amdgcn_sched_barrier(0);
@@ -1582,7 +1603,7 @@ __global__ __launch_bounds__(TOPK_THREADS, TVBF_DMA_WGS) void cosine_topk_dma_ke
                         const int c = (int)col0 + 2 * (idx & 48) + (idx & 3) + 2 * (idx & 12) + 4 * half;  // 32 j + (r & 3) + 8 (r >> 2)
                         const u64 key = make_key(v, c);
                         bool cand = has && v >= thr && key > mkey;
-#ifdef TVBF_DIAG_TIMELINE
+#if defined(TVBF_DIAG_TIMELINE) && !defined(TVBF_DIAG_TOPSPLIT)
                         dl_cand += __builtin_popcountll(__ballot(cand));
                         ++dl_pops;
 #endif
@@ -1599,7 +1620,7 @@ __global__ __launch_bounds__(TOPK_THREADS, TVBF_DMA_WGS) void cosine_topk_dma_ke
                                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                                 __builtin_amdgcn_wave_barrier();
                                 while (full) {
-#ifdef TVBF_DIAG_TIMELINE
+#if defined(TVBF_DIAG_TIMELINE) && !defined(TVBF_DIAG_TOPSPLIT)
                                     ++dl_compact;
 #endif
                                     const int l = (int)__builtin_ctzll(full) & 31;
@@ -1709,7 +1730,7 @@ __global__ __launch_bounds__(TOPK_THREADS, TVBF_DMA_WGS) void cosine_topk_dma_ke
                     while (todo) {
                         const int l = (int)__builtin_ctzll(todo);
                         todo &= todo - 1ull;
-                        col_refresh_bound(a, __shfl(pend_row, l, 64), __shfl(pend_w0, l, 64), reinterpret_cast<u64*>(scratch), lane);
+                        col_refresh_bound(a, __shfl(pend_row, l, 64), __shfl(pend_w0, l, 64), lane);
                     }
                 } while (again);
             }
@@ -1755,7 +1776,7 @@ __global__ __launch_bounds__(TOPK_THREADS, TVBF_DMA_WGS) void cosine_topk_dma_ke
         __syncthreads();
         unsigned queued_cols = *lcnt;
         if (queued_cols > (unsigned)a.col_lds) queued_cols = (unsigned)a.col_lds;
-        col_drain(a, lrowg, lkey, queued_cols, tid, lane, reinterpret_cast<u64*>(scratch));
+        col_drain(a, lrowg, lkey, queued_cols, tid, lane);
     }
 #ifdef TVBF_DIAG_TIMELINE
     if (dl_buf && lane == 0) {
