@@ -185,7 +185,7 @@ int tvbf_cosine_topk_static_f32(const float* Zq, int64_t nq, int64_t q_row0, con
  * spend most of their time on lists that have not seen enough columns to reject anything; a
  * stored matrix of this size is cheaper.  Larger catalogues take the fused sweeps described
  * below, which need at least 16 blocks of 128 rows.
- * Every show has a buffer of 1024 column-side candidates; should one overflow, the show is
+ * Every show has a buffer of 1024 column-side candidates (2048 for k > 64); should one overflow, the show is
  * flagged and a plain sweep restricted to the 128-row blocks that hold flagged shows recomputes
  * their lists on the device, without host synchronisation (it returns at once when nothing is
  * flagged).
@@ -255,7 +255,7 @@ int tvbf_topk_finish(int64_t nq, int k, int slots, int32_t* out_idx, float* out_
  *                           sweep raises entries of this array as column-side candidates arrive); state / state_bytes: device buffer of
  *                           tvbf_topk_colside_bytes(n_total, cap) bytes that starts with the
  *                           overflow words: word 0 = some buffer overflowed, words 4 .. 4+n_total-1
- *                           = this show's buffer overflowed; cap: candidates kept per show (<= 1024)
+ *                           = this show's buffer overflowed; cap: candidates kept per show (<= 2048)
  *   tvbf_topk_colside_begin clears the overflow words, the counters and the buffers
  *   tvbf_topk_colside_reset the same for a state that went through begin and one job with the
  *                           same n_total and cap: clears only the entries that job wrote

@@ -4,7 +4,7 @@
     python tools/colside_hist.py [n] [d] [k]
 
 Reads the per-show counters behind the lists in the workspace of engine.cosine_topk_symmetric
-(layout: [bounds and list slots][16 bytes of summary][n flags][n counters][n x 1024 keys])."""
+(layout: [bounds and list slots][16 bytes of summary][n flags][n counters][n x cap keys], cap = 1024, or 2048 for k > 64)."""
 import sys
 from pathlib import Path
 
@@ -40,11 +40,12 @@ ws = torch.empty((nbytes + 15) // 16 * 2, dtype=torch.int64, device=dev)
 engine.cosine_topk_symmetric(z, k, 0.1, workspace=ws)
 torch.cuda.synchronize()
 cnt_bytes = (n * 4 + 15) // 16 * 16
-state_bytes = 16 + 2 * cnt_bytes + n * 1024 * 8
+cap = 1024 if k <= 64 else 2048
+state_bytes = 16 + 2 * cnt_bytes + n * cap * 8
 off = nbytes - state_bytes + 16 + cnt_bytes
 cnt = ws.view(torch.uint8)[off:off + 4 * n].view(torch.int32).cpu().numpy()
 print(f"n={n} d={d} k={k}: {cnt.sum()} entries, mean {cnt.mean():.1f}, max {cnt.max()}")
-edges = [0, 32, 64, 128, 192, 256, 384, 512, 640, 768, 896, 1024, 1 << 30]
+edges = [0, 32, 64, 128, 192, 256, 384, 512, 640, 768, 896, 1024, 2048, 1 << 30]
 h, _ = np.histogram(cnt, bins=edges)
 for a, b, c in zip(edges, edges[1:], h):
     print(f"  [{a:5d}, {b if b < 1 << 30 else 'inf':>5}) {c:7d} shows  {100 * c / n:5.1f} %   {100 * cnt[(cnt >= a) & (cnt < b)].sum() / max(cnt.sum(), 1):5.1f} % of entries")

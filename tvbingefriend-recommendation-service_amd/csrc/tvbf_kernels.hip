@@ -2564,8 +2564,9 @@ __global__ __launch_bounds__(64 * BMERGE_ROWS) void bound_merge_kernel(const u64
 // reach the show's final bound are packed into LDS, ranked by counting, and the K best written
 // in the partial-list format (descending, empty slots = sentinel).
 // --------------------------------------------------------------------------
-constexpr int COL_CAP_MAX = 1024;
+constexpr int COL_CAP_MAX = 2048;
 constexpr int COLRED_ROWS = 4;
+static size_t colred_lds_bytes(int col_cap) { return (size_t)COLRED_ROWS * col_cap * sizeof(u64); }
 
 __global__ __launch_bounds__(64 * COLRED_ROWS) void col_reduce_kernel(const unsigned* __restrict__ col_cnt,
                                                                       const u64* __restrict__ col_buf, int col_cap,
@@ -2573,12 +2574,12 @@ __global__ __launch_bounds__(64 * COLRED_ROWS) void col_reduce_kernel(const unsi
                                                                       int k, float min_similarity,
                                                                       u64* __restrict__ out, int64_t row0) {
     // shows row0 .. row0 + n - 1 of the buffers; list i of `out` belongs to show row0 + i
-    __shared__ u64 buf[COLRED_ROWS][COL_CAP_MAX];
+    extern __shared__ __attribute__((aligned(16))) unsigned char colred_smem[];  // [COLRED_ROWS][col_cap] keys
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int64_t row = (int64_t)blockIdx.x * COLRED_ROWS + wave;
     if (row >= n) return;
-    u64* b = buf[wave];
+    u64* b = reinterpret_cast<u64*>(colred_smem) + (size_t)wave * col_cap;
     int m = (int)col_cnt[row0 + row];
     if (m > col_cap) m = col_cap;
     const u64 thr = bound[row0 + row];  // K-th key of one of the show's own lists (or the empty-list sentinel)
@@ -3747,8 +3748,10 @@ int tvbf_topk_accumulate_sym_f32(const float* Zq, int64_t nq, int64_t q_row0, in
                                    dim3(TOPK_THREADS), lds_half, st, a);
         }
     }
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(col_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)colred_lds_bytes(a.col_cap)));
     hipLaunchKernelGGL(col_reduce_kernel, dim3((unsigned)((nq + COLRED_ROWS - 1) / COLRED_ROWS)), dim3(64 * COLRED_ROWS),
-                       0, st, a.col_cnt, a.col_buf, a.col_cap, a.col_bound, nq, k, min_similarity,
+                       colred_lds_bytes(a.col_cap), st, a.col_cnt, a.col_buf, a.col_cap, a.col_bound, nq, k, min_similarity,
                        lists + (size_t)done * nq * k, q_row0);
     HIP_TRY(hipGetLastError());
     *slots_used = total;
@@ -3801,8 +3804,10 @@ int tvbf_topk_colside_reduce(const tvbf_colside* cs, int64_t row0, int64_t rows,
     if (rows == 0) return TVBF_OK;
     if (min_similarity < -FLT_MAX) min_similarity = -FLT_MAX;
     const char* st = reinterpret_cast<const char*>(cs->state);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(col_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)colred_lds_bytes((int)cs->cap)));
     hipLaunchKernelGGL(col_reduce_kernel, dim3((unsigned)((rows + COLRED_ROWS - 1) / COLRED_ROWS)),
-                       dim3(64 * COLRED_ROWS), 0, (hipStream_t)stream,
+                       dim3(64 * COLRED_ROWS), colred_lds_bytes((int)cs->cap), (hipStream_t)stream,
                        reinterpret_cast<const unsigned*>(st + cs_cnt_off(cs->n_total)),
                        reinterpret_cast<const u64*>(st + cs_buf_off(cs->n_total)), (int)cs->cap, reinterpret_cast<const u64*>(cs->col_bound), rows, k,
                        min_similarity, reinterpret_cast<u64*>(lists), row0);
@@ -3998,7 +4003,9 @@ static SymPlan make_sym_plan(int64_t n, int64_t d, int k) {
     if (!plan_sym_sweeps(&sw, n, cus, slots - 1)) return sp;
     sp.s_sym = sw.sweep_slots + 1;
     sp.s_full = plan_items(&a, SYM_OFF, n, 1, 1, 0, tiles_of(n), cus, 2, slots < 16 ? slots : 16, true);
-    sp.col_cap = COL_CAP_MAX;
+    // entries per show: about 6 K arrive in an ordinary catalogue (the busiest show of 100,000 took 307
+    // at K = 20, 541 at K = 50 and 1056 at K = 100)
+    sp.col_cap = k <= 64 ? 1024 : COL_CAP_MAX;
     if (const char* e = getenv("TVBF_SYM_COL_CAP")) sp.col_cap = atoi(e);  // tuning / test aid
     if (sp.col_cap < 1) sp.col_cap = 1;
     if (sp.col_cap > COL_CAP_MAX) sp.col_cap = COL_CAP_MAX;

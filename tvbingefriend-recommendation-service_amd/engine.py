@@ -689,7 +689,7 @@ class ColumnSide:
         self.n_total, self.cap, self.dev = int(n_total), int(cap), torch.device(device)
         self.bytes = int(self.lib.tvbf_topk_colside_bytes(self.n_total, self.cap))
         if not self.bytes:
-            raise ValueError("n_total >= 1 and 1 <= cap <= 1024")
+            raise ValueError("n_total >= 1 and 1 <= cap <= 2048")
         self.state = torch.empty((self.bytes + 15) // 16 * 2, dtype=torch.int64, device=self.dev)
         self._struct = None
         self._clean = False
