@@ -12,4 +12,5 @@ run n100k_d1024_k100_symmetric --k 100
 run n100k_d1024_k20_dense_symmetric --data dense
 run n10k_d512_k20_dense --shows 10000 --dims 512 --data dense --steps 20
 run n30k_d576_k20 --shows 30000 --dims 576
+run n80k_d576_k20 --shows 80000 --dims 576
 for f in gpurun_out/${R}_*.txt; do echo "== $f"; cut -c1-180 $f | grep -E "cosine|matrix_rows|metric" | cut -c1-180; done

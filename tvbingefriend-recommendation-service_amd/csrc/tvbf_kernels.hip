@@ -489,13 +489,14 @@ __device__ static inline void merge_row_global(u64* stg, unsigned* cnt, u64* mke
         }
     }
     int n_real = 0;
+    u64 kth = 0ull;  // the new K-th key, in the lane that holds it
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
         n_real += __builtin_popcountll(__ballot(real[u]));
         if (real[u] && rk[u] < k) __hip_atomic_store(glist + rk[u], my[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (real[u] && rk[u] == k - 1) {
             *mkey = my[u];
-            if (gbound) atomicMax(reinterpret_cast<unsigned long long*>(gbound), (unsigned long long)my[u]);
+            kth = my[u];
         }
     }
     for (int j = n_real + lane; j < k; j += 64) __hip_atomic_store(glist + j, empty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -503,6 +504,9 @@ __device__ static inline void merge_row_global(u64* stg, unsigned* cnt, u64* mke
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    // behind the fence: the fence waits for every memory operation in flight, and this device-scope
+    // atomic (the row's bound, read by other workgroups) takes several microseconds to be acknowledged
+    if (kth != 0ull && gbound) atomicMax(reinterpret_cast<unsigned long long*>(gbound), (unsigned long long)kth);
 }
 
 // MODE_STATS: the dense-matrix orientation with an epilogue that folds the strict upper
@@ -3961,14 +3965,16 @@ struct SymPlan {
     size_t off_state, state_bytes, bytes;  // the column-side state behind it
 };
 
-// Catalogues up to this many shows take the matrix route (n^2 floats: 2.4 GB at the limit).  Below
+// Catalogues up to this many shows take the matrix route (n^2 floats: 5.4 GB at the limit).  Below
 // a few thousand columns per list the fused epilogue spends more time on cold lists than the
 // matrix pipe spends on the products; storing and scanning n^2 floats costs 8 n^2 bytes of
 // traffic instead, which at these sizes is the smaller price (measured at D = 512: 0.64 against
-// 1.25 ms at n = 10,000, 1.56 against 2.12 ms at 16,384, 3.04 against 3.66 ms at 24,000; the
-// fused sweeps win from about 40,000 shows on, and their workspace grows with n, not n^2).
+// 1.25 ms at n = 10,000, 1.56 against 2.12 ms at 16,384, 3.04 against 3.66 ms at 24,000; at
+// D = 576: 4.47 against 4.72 ms at 30,000, 6.32 against 6.59 ms at 36,000, 9.44 against 9.25 ms
+// at 44,000 -- the fused sweeps win from about 40,000 shows on, and their workspace grows with n,
+// not n^2).
 // TVBF_SYM_ROUTE=fused|matrix overrides (test / tuning aid; matrix up to 65,536).
-constexpr int64_t MATRIX_ROUTE_MAX_N = 24576;
+constexpr int64_t MATRIX_ROUTE_MAX_N = 36864;
 constexpr int64_t MATRIX_ROUTE_HARD_MAX_N = 65536;
 
 static bool sym_route_matrix(int64_t n, int64_t d) {
