@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Random shapes through every route of the top-K sweep (run on the GPU box):
 
-    python tools/fuzz_routes.py [first_seed] [count] [big]
+    python tests/fuzz_routes.py [first_seed] [count] [big]
 
 For every seed: a random catalogue (dense gaussian, hybrid-like, few distinct rows, one-hot rows),
 random n, d, K and threshold.  The general sweep on the LDS-DMA loop is the reference point; the

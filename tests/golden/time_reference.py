@@ -1,7 +1,7 @@
 """Times the REAL reference beside the oracle port on the same inputs (build container only: the
 reference tree does not travel to the GPU box).
 
-    cd /tmp && PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=/root/reference:/root/repo python /root/repo/tools/time_reference.py
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=/root/reference:/root/repo python /root/repo/tests/golden/time_reference.py
 
 Matrix mode: SimilarityComputer.compute_all_similarities (ml/similarity_computer.py:132-169) followed
 by the selection of scripts/populate_database.py:195-218 on every row (np.argsort(row)[::-1] + walk).
@@ -19,7 +19,7 @@ from pathlib import Path
 
 import numpy as np
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 

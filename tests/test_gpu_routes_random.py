@@ -1,7 +1,7 @@
 """Random catalogues (dense, hybrid-like, few distinct rows, one-hot rows), sizes, K and thresholds
 through every route of the top-K sweep -- LDS-DMA loop, register-staged loop, lists in LDS or in
 global memory, fused symmetric sweeps, stored-matrix route: identical lists bit for bit, and the
-float64 oracle agrees on 256 sampled rows (tools/fuzz_routes.py holds the generator; the counterpart
+float64 oracle agrees on 256 sampled rows (tests/fuzz_routes.py holds the generator; the counterpart
 in the reference is the per-show loop of scripts/populate_database.py:170-218)."""
 
 from __future__ import annotations
@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 
 def test_random_shapes_every_route_identical(pkg, device):
-    spec = importlib.util.spec_from_file_location("fuzz_routes", Path(__file__).resolve().parent.parent / "tools" / "fuzz_routes.py")
+    spec = importlib.util.spec_from_file_location("fuzz_routes", Path(__file__).resolve().parent / "fuzz_routes.py")
     fuzz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fuzz)
     assert fuzz.run_seeds(0, 48) == 0
