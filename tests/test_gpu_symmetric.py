@@ -65,14 +65,17 @@ def _assert_same(a, b, what):
     assert np.array_equal(_to_np(a.score), _to_np(b.score)), what
 
 
+@pytest.mark.parametrize("own", ["matrix", "fused"])
 @pytest.mark.parametrize("n,shards", [(1500, 16), (1500, 5), (1500, 3), (1500, 2), (2049, 4), (2049, 7), (4000, 16)])
-def test_symmetric_equals_plain_hybrid(pkg, device, monkeypatch, n, shards):
-    """Odd and even shard counts, ragged last shard and last tile: identical lists."""
+def test_symmetric_equals_plain_hybrid(pkg, device, monkeypatch, n, shards, own):
+    """Odd and even shard counts, ragged last shard and last tile: identical lists -- with the
+    shards' own blocks stored as a batch of matrices (the default) and swept by the fused kernel."""
     import torch
 
     from tvbingefriend_recommendation_service_amd import engine
 
     monkeypatch.setenv("TVBF_SYM_SHARDS", str(shards))
+    monkeypatch.setenv("TVBF_SYM_OWN", own)
     z, _, _ = _z_hybrid(device, n, seed=200 + n)
     assert z.shape[1] % 64 == 0
     for k, ms in ((20, 0.1), (7, 0.3)):
@@ -94,6 +97,7 @@ def test_symmetric_two_levels_equals_plain(pkg, device, monkeypatch, n, shards, 
 
     monkeypatch.setenv("TVBF_SYM_SHARDS", str(shards))
     monkeypatch.setenv("TVBF_SYM_RING", str(ring))
+    monkeypatch.setenv("TVBF_SYM_OWN", "fused")  # the rings belong to the fused own-block sweeps
     z, _, _ = _z_hybrid(device, n, seed=900 + n + ring)
     # (31, 0.05): lists in global memory; hundreds of shows tie at two shared metadata values, so a
     # few column buffers may run full on these small matrices -- the lists must agree either way

@@ -1857,6 +1857,12 @@ struct TriArgs {
     const unsigned* st_gate;    // TRI_STATS: when given, the sweep runs only if this word is non-zero
     GramStatsWs* bn_ws;         // TRI_BAND
     unsigned* bn_buf;           // TRI_BAND: bn_ws->buf_cap keys
+    // TRI_STORE, batch of diagonal blocks (nblk > 0): block b = row blocks [blk_rb[b], blk_rb[b + 1]) of
+    // z against themselves, its triangle stored in rows blk_rb[b] * 128 ... of `out` (columns counted
+    // from the block's first row); the triangles form one line of tiles, blk_prefix[b] before block b
+    int nblk;
+    int blk_rb[MAX_TOP_SHARDS + 1];
+    int64_t blk_prefix[MAX_TOP_SHARDS + 1];
 };
 
 // tiles of the row blocks before row block rb
@@ -1924,7 +1930,6 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tri_dma_kernel(TriArgs
     if ((int)blockIdx.x >= a.items / 2)
         for (int u = 0; u < TVBF_TRI_STAGGER; ++u) __builtin_amdgcn_s_sleep(8);
 #endif
-    const int64_t T = a.tiles;
     // This workgroup's stretch.  With an even number of workgroups the line is first cut into
     // items / 2 equal parts and each part into two halves, for workgroups w and w + items / 2: the
     // dispatcher places those two on one compute unit (workgroups go round the compute units in
@@ -1942,20 +1947,35 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tri_dma_kernel(TriArgs
         x_pos = (a.total_tiles * (int64_t)blockIdx.x) / a.items;
         x_end = (a.total_tiles * ((int64_t)blockIdx.x + 1)) / a.items;
     }
-    // row block of the first tile: the largest rb with tri_prefix(rb) <= x_pos
+#pragma nounroll
+    while (x_pos < x_end) {  // one segment: a run of column tiles of one row block
+    // the triangle the segment lies in: the whole matrix, or one diagonal block of a batch
+    const float* zb = a.z;
+    float* ob = a.out;
+    int64_t n_loc = a.n, T = a.tiles, x_loc = x_pos;
+    if (a.nblk > 0) {
+        int blk = 0;
+        while (blk + 1 < a.nblk && a.blk_prefix[blk + 1] <= x_pos) ++blk;
+        const int64_t row0 = (int64_t)a.blk_rb[blk] * BM;
+        int64_t row1 = (int64_t)a.blk_rb[blk + 1] * BM;
+        if (row1 > a.n) row1 = a.n;
+        zb = a.z + row0 * a.ld;
+        ob = a.out + row0 * a.ldo;
+        n_loc = row1 - row0;
+        T = a.blk_rb[blk + 1] - a.blk_rb[blk];
+        x_loc = x_pos - a.blk_prefix[blk];
+    }
+    // row block of the first tile: the largest rb with tri_prefix(rb) <= x_loc
     int rb = 0;
     {
         int lo = 0, hi = (int)T - 1;
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
-            if (tri_prefix(mid, T) <= x_pos) lo = mid; else hi = mid - 1;
+            if (tri_prefix(mid, T) <= x_loc) lo = mid; else hi = mid - 1;
         }
         rb = lo;
     }
-#pragma nounroll
-    while (x_pos < x_end) {  // one segment: a run of column tiles of one row block
-    while (tri_prefix(rb + 1, T) <= x_pos) ++rb;
-    const int tile_begin = rb + (int)(x_pos - tri_prefix(rb, T));
+    const int tile_begin = rb + (int)(x_loc - tri_prefix(rb, T));
     const int tile_end = x_pos + (T - tile_begin) > x_end ? tile_begin + (int)(x_end - x_pos) : (int)T;
     x_pos += tile_end - tile_begin;
     const int64_t q0 = (int64_t)rb * BM;
@@ -1963,16 +1983,16 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tri_dma_kernel(TriArgs
     unsigned qoff;
     {
         int64_t r = lrow;
-        if (q0 + r > a.n - 1) r = a.n - 1 - q0;
+        if (q0 + r > n_loc - 1) r = n_loc - 1 - q0;
         qoff = (unsigned)((r * a.ld + half * 4) * 4);
     }
     unsigned coff[4];
     const char* tile_ptr = nullptr;
     auto set_tile = [&](int ct) {
         const int64_t trow = (int64_t)ct * BN;
-        const int last = (int)(a.n - 1 - trow < BN ? a.n - 1 - trow : BN);  // rows past the end repeat the last row
+        const int last = (int)(n_loc - 1 - trow < BN ? n_loc - 1 - trow : BN);  // rows past the end repeat the last row
         {
-            const uint64_t p = reinterpret_cast<uint64_t>(a.z + trow * a.ld);
+            const uint64_t p = reinterpret_cast<uint64_t>(zb + trow * a.ld);
             const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p);
             const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
             tile_ptr = reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
@@ -1993,7 +2013,7 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tri_dma_kernel(TriArgs
             dma16(window, cb, coff[i], buffer + i * 1024 + wave * 256);
         }
     };
-    const char* qbase = reinterpret_cast<const char*>(a.z + q0 * a.ld);
+    const char* qbase = reinterpret_cast<const char*>(zb + q0 * a.ld);
     f32x4 qreg[2][4];
     auto load_q = [&](int kb, f32x4(&q)[4]) {
         const char* qb = qbase + (size_t)kb * (BK * 4);
@@ -2083,15 +2103,15 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tri_dma_kernel(TriArgs
                 if (EPI == TRI_STORE) {
                     // Addresses are a uniform base (tile origin and the register's column, in scalar
                     // registers) plus one 32-bit per-lane byte offset per orientation.
-                    char* const obase = reinterpret_cast<char*>(a.out);
+                    char* const obase = reinterpret_cast<char*>(ob);
                     const int64_t row_bytes = a.ldo * 4;
                     unsigned voff_n = (unsigned)(((int64_t)lrow * a.ldo + 4 * half) * 4);  // the tile itself: row lrow
                     unsigned voff_t = (unsigned)(((int64_t)(4 * half) * a.ldo + lrow) * 4);  // its transpose: column lrow
                     asm volatile("" : "+v"(voff_n), "+v"(voff_t));
-                    if (qr < a.n) {
+                    if (qr < n_loc) {
                         char* const nb = obase + (q0 * a.ldo + col0) * 4;
                         char* const tb = obase + (col0 * a.ldo + q0) * 4;
-                        if (col0 + BN <= a.n) {  // every column of the tile exists
+                        if (col0 + BN <= n_loc) {  // every column of the tile exists
 #pragma unroll
                             for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -2107,7 +2127,7 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tri_dma_kernel(TriArgs
                                             acc[j][r];
                             }
                         } else {  // last column tile: columns past the end are left out
-                            int rel_end = (int)(a.n - col0) - 4 * half;
+                            int rel_end = (int)(n_loc - col0) - 4 * half;
                             asm volatile("" : "+v"(rel_end));
 #pragma unroll
                             for (int j = 0; j < NJ; ++j)
@@ -2126,10 +2146,10 @@ __global__ __launch_bounds__(TOPK_THREADS, 2) void cosine_tri_dma_kernel(TriArgs
                     // of the tile counts: no test per score there (uniform branch).
                     const int sh = st_shift(a.st_level), prev = a.st_level == 0 ? 32 : st_shift(a.st_level - 1);
                     const unsigned mask = (1u << st_bits(a.st_level)) - 1u;
-                    const bool interior = ct > rb && col0 + BN <= a.n && q0 + BM <= a.n;
+                    const bool interior = ct > rb && col0 + BN <= n_loc && q0 + BM <= n_loc;
                     // this lane's row relative to the tile's first column (small numbers: 32-bit tests)
-                    int rel_row = (int)(qr - col0) - 4 * half, rel_end = (int)(a.n - col0) - 4 * half;
-                    if (qr >= a.n) rel_row = 1 << 20;  // a repeated row past the end: nothing counts
+                    int rel_row = (int)(qr - col0) - 4 * half, rel_end = (int)(n_loc - col0) - 4 * half;
+                    if (qr >= n_loc) rel_row = 1 << 20;  // a repeated row past the end: nothing counts
                     asm volatile("" : "+v"(rel_row), "+v"(rel_end));
                     auto fold_band = [&](float v, bool counts) {  // called by all lanes together
                         const unsigned key = f32_to_ordered(v);
@@ -2260,13 +2280,26 @@ __global__ __launch_bounds__(256) void matrix_rows_topk_kernel(const float* __re
                                                                int32_t* __restrict__ out_idx,
                                                                float* __restrict__ out_score,
                                                                int32_t* __restrict__ out_count, int64_t col_base,
-                                                               u64* __restrict__ slot, u64* __restrict__ bound) {
+                                                               u64* __restrict__ slot, u64* __restrict__ bound,
+                                                               int bshards, int brb) {
     __shared__ u64 buf_all[4][MROW_CAP];
     __shared__ u64 mkey_all[4];
     __shared__ unsigned cnt_all[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t row = (int64_t)blockIdx.x * 4 + wave;
     if (row >= n) return;  // wave-private state only: no workgroup barrier below
+    // bshards > 0: the matrix holds a batch of diagonal blocks (cosine_tri_dma_kernel, nblk > 0) --
+    // block s = row blocks [s * brb / bshards, (s + 1) * brb / bshards) of the n rows; row `row` holds
+    // its scores against the rows of its own block, counted from the block's first row
+    int64_t first = 0;  // first row of this row's block
+    if (bshards > 0) {
+        const int64_t blk = ((row / BM + 1) * bshards - 1) / brb;
+        first = (blk * brb) / bshards * BM;
+        int64_t end = ((blk + 1) * brb) / bshards * BM;
+        if (end > n) end = n;
+        n = end - first;
+        col_base += first;
+    }
     u64* buf = buf_all[wave];
     if (lane == 0) {
         mkey_all[wave] = sentinel_key(min_similarity);
@@ -2281,7 +2314,7 @@ __global__ __launch_bounds__(256) void matrix_rows_topk_kernel(const float* __re
     // a quarter of one of 128, and the threshold it raises is fresher
     const unsigned cap = k + 28 <= 64 ? 64u : (unsigned)MROW_CAP;
     const float* s = m + row * ldm;
-    const int64_t skip = exclude_self ? row : -1;
+    const int64_t skip = exclude_self ? row - first : -1;
     // 512 scores per step (two 16-byte loads per lane); the loads of the next step are issued before
     // this step's scores are looked at, so a row's scan is not one memory latency per step
     auto load4 = [&](int64_t c) {
@@ -3298,13 +3331,18 @@ struct SymSweeps {
     int sweep_slots;                   // sum of slots[]
 };
 
-static bool plan_sym_sweeps(SymSweeps* sw, int64_t nq, int cus, int budget) {
+// own_done: the shards' own blocks are dealt with elsewhere (stored as matrices); only the half
+// sweep over the shards is planned.
+static bool plan_sym_sweeps(SymSweeps* sw, int64_t nq, int cus, int budget, bool own_done = false) {
     const int row_blocks = (int)((nq + BM - 1) / BM);
     const int shards = sym_shards(row_blocks);
     if (shards < 2) return false;
     const int ring = sym_ring(row_blocks, shards);
     memset(sw, 0, sizeof(*sw));
-    if (ring > 1) {
+    if (own_done) {
+        sw->n = 1;
+        sw->sym[0] = SYM_HALF, sw->shards[0] = shards, sw->ring[0] = shards;
+    } else if (ring > 1) {
         sw->n = 3;
         sw->sym[0] = SYM_DIAG, sw->shards[0] = shards * ring, sw->ring[0] = ring;
         sw->sym[1] = SYM_HALF, sw->shards[1] = shards * ring, sw->ring[1] = ring;
@@ -3653,10 +3691,12 @@ int tvbf_topk_accumulate_ex_f32(const float* Zq, int64_t nq, int64_t q_row0, int
 // The symmetric sweep of a block of rows against itself inside an incremental sequence: the
 // own-columns sweep, the half sweep (column side into the caller's column-side state, at the
 // block's global rows) and the reduction of those buffers into one more list slot.
-int tvbf_topk_accumulate_sym_f32(const float* Zq, int64_t nq, int64_t q_row0, int64_t d, int64_t ld, int k,
-                                 float min_similarity, int exclude_self, void* workspace, size_t workspace_bytes,
-                                 int slot0, int max_slots, int* slots_used, const tvbf_colside* colside,
-                                 void* stream) {
+// own_done: every shard's own block (its rows against its own columns) has already been written
+// to a list slot below slot0 and has raised the bounds; only the half sweep over the shards runs.
+static int accumulate_sym_impl(const float* Zq, int64_t nq, int64_t q_row0, int64_t d, int64_t ld, int k,
+                               float min_similarity, int exclude_self, void* workspace, size_t workspace_bytes,
+                               int slot0, int max_slots, int* slots_used, const tvbf_colside* colside,
+                               void* stream, bool own_done) {
     if (!slots_used) return fail(TVBF_E_BAD_ARG, "slots_used must be non-null");
     *slots_used = 0;
     if (!colside) return fail(TVBF_E_BAD_ARG, "the symmetric sweep needs a column-side state");
@@ -3679,7 +3719,7 @@ int tvbf_topk_accumulate_sym_f32(const float* Zq, int64_t nq, int64_t q_row0, in
     const int budget = max_slots - 1;  // one slot is the reduced column side
     if (budget < 2) return fail(TVBF_E_BAD_ARG, "the symmetric sweep needs at least 3 slots");
     SymSweeps sw;
-    if (!col_lds || !plan_sym_sweeps(&sw, nq, cus, budget))
+    if (!col_lds || !plan_sym_sweeps(&sw, nq, cus, budget, own_done))
         return fail(TVBF_E_BAD_SHAPE, "the symmetric sweep needs d %% 64 == 0 and at least 16 row blocks");
     const size_t lds_diag = topk_lds_bytes(k, d);
     const int total = sw.sweep_slots + 1;
@@ -3760,6 +3800,14 @@ int tvbf_topk_accumulate_sym_f32(const float* Zq, int64_t nq, int64_t q_row0, in
     HIP_TRY(hipGetLastError());
     *slots_used = total;
     return TVBF_OK;
+}
+
+int tvbf_topk_accumulate_sym_f32(const float* Zq, int64_t nq, int64_t q_row0, int64_t d, int64_t ld, int k,
+                                 float min_similarity, int exclude_self, void* workspace, size_t workspace_bytes,
+                                 int slot0, int max_slots, int* slots_used, const tvbf_colside* colside,
+                                 void* stream) {
+    return accumulate_sym_impl(Zq, nq, q_row0, d, ld, k, min_similarity, exclude_self, workspace, workspace_bytes, slot0,
+                               max_slots, slots_used, colside, stream, false);
 }
 
 size_t tvbf_topk_colside_bytes(int64_t n_total, int cap) {
@@ -3963,7 +4011,35 @@ struct SymPlan {
     int col_cap;
     size_t topk_bytes;  // bounds and list slots: an ordinary top-K workspace
     size_t off_state, state_bytes, bytes;  // the column-side state behind it
+    // fused route: the shards' own blocks as a batch of stored matrices (own_bytes > 0), between
+    // the lists and the column-side state
+    int shards;
+    int64_t own_ldm;
+    size_t off_own, own_bytes;
 };
+
+// The shards' own blocks of the fused route -- 1 / shards of all pairs, each list still cold -- as
+// stored matrices (cosine_tri_dma_kernel with nblk > 0: every tile on or above a block's diagonal
+// once; matrix_rows_topk_kernel selects), where the fused own-column sweeps compute both orders
+// and pay for cold lists: n x (rows of the largest shard) floats, taken while that is at most 8 GiB.
+// TVBF_SYM_OWN=fused|matrix overrides (test / tuning aid).
+constexpr size_t OWN_MATRIX_MAX_BYTES = (size_t)8 << 30;
+
+static size_t sym_own_matrix_bytes(int64_t n, int shards, int64_t* ldm) {
+    const int64_t row_blocks = (n + BM - 1) / BM;
+    int64_t widest = 0;
+    for (int v = 0; v < shards; ++v) {
+        const int64_t blocks = ((int64_t)(v + 1) * row_blocks) / shards - ((int64_t)v * row_blocks) / shards;
+        if (blocks > widest) widest = blocks;
+    }
+    *ldm = widest * BM;  // a multiple of 32 floats: rows start on 128-byte boundaries
+    const size_t bytes = (size_t)n * (size_t)*ldm * sizeof(float);
+    if (const char* e = getenv("TVBF_SYM_OWN")) {
+        if (!strcmp(e, "fused")) return 0;
+        if (!strcmp(e, "matrix")) return bytes;
+    }
+    return bytes <= OWN_MATRIX_MAX_BYTES ? bytes : 0;
+}
 
 // Catalogues up to this many shows take the matrix route (n^2 floats: 5.4 GB at the limit).  Below
 // a few thousand columns per list the fused epilogue spends more time on cold lists than the
@@ -4006,8 +4082,15 @@ static SymPlan make_sym_plan(int64_t n, int64_t d, int k) {
     TopkArgs a;
     memset(&a, 0, sizeof(a));
     SymSweeps sw;
-    if (!plan_sym_sweeps(&sw, n, cus, slots - 1)) return sp;
-    sp.s_sym = sw.sweep_slots + 1;
+    sp.shards = shards;
+    sp.own_bytes = sym_own_matrix_bytes(n, shards, &sp.own_ldm);
+    if (sp.own_bytes) {  // one slot for the own blocks, the half sweep's, one for the reduced column side
+        if (!plan_sym_sweeps(&sw, n, cus, slots - 2, true)) return sp;
+        sp.s_sym = sw.sweep_slots + 2;
+    } else {
+        if (!plan_sym_sweeps(&sw, n, cus, slots - 1)) return sp;
+        sp.s_sym = sw.sweep_slots + 1;
+    }
     sp.s_full = plan_items(&a, SYM_OFF, n, 1, 1, 0, tiles_of(n), cus, 2, slots < 16 ? slots : 16, true);
     // entries per show: about 6 K arrive in an ordinary catalogue (the busiest show of 100,000 took 307
     // at K = 20, 541 at K = 50 and 1056 at K = 100)
@@ -4016,7 +4099,8 @@ static SymPlan make_sym_plan(int64_t n, int64_t d, int k) {
     if (sp.col_cap < 1) sp.col_cap = 1;
     if (sp.col_cap > COL_CAP_MAX) sp.col_cap = COL_CAP_MAX;
     sp.topk_bytes = ws_bound_bytes(n) + (size_t)(sp.s_sym + sp.s_full) * ws_slot_bytes(n, k);
-    sp.off_state = (sp.topk_bytes + 15) / 16 * 16;
+    sp.off_own = (sp.topk_bytes + 15) / 16 * 16;
+    sp.off_state = sp.off_own + (sp.own_bytes + 15) / 16 * 16;
     sp.state_bytes = cs_buf_off(n) + (size_t)n * sp.col_cap * 8;
     sp.bytes = sp.off_state + sp.state_bytes;
     sp.ok = true;
@@ -4045,6 +4129,26 @@ static void fill_tri_args(TriArgs* a, const float* Z, int64_t n, int64_t d, int6
     a->items = tri_items(a->total_tiles, device_cus());
 }
 
+// the diagonal blocks of the `shards` shards of an n-row matrix as one batch (see TriArgs::nblk)
+static void fill_tri_batch(TriArgs* a, const float* Z, int64_t n, int64_t d, int64_t ld, int shards) {
+    memset(a, 0, sizeof(*a));
+    a->z = Z;
+    a->n = n;
+    a->ld = ld;
+    a->d = (int)d;
+    a->tiles = tiles_of(n);
+    a->nblk = shards;
+    const int64_t row_blocks = (n + BM - 1) / BM;
+    a->blk_prefix[0] = 0;
+    for (int v = 0; v <= shards; ++v) a->blk_rb[v] = (int)(((int64_t)v * row_blocks) / shards);
+    for (int v = 0; v < shards; ++v) {
+        const int64_t t = a->blk_rb[v + 1] - a->blk_rb[v];
+        a->blk_prefix[v + 1] = a->blk_prefix[v] + tri_prefix(t, t);
+    }
+    a->total_tiles = a->blk_prefix[shards];
+    a->items = tri_items(a->total_tiles, device_cus());
+}
+
 size_t tvbf_cosine_topk_sym_workspace_bytes(int64_t n, int64_t d, int k) {
     const SymPlan sp = make_sym_plan(n, d, k);
     return sp.ok ? sp.bytes : 0;
@@ -4054,6 +4158,13 @@ int64_t tvbf_cosine_topk_sym_tiles(int64_t n, int64_t d, int k) {
     const SymPlan sp = make_sym_plan(n, d, k);
     if (!sp.ok) return 0;
     if (sp.matrix) return tri_prefix(tiles_of(n), tiles_of(n));
+    if (sp.own_bytes) {  // the diagonal blocks' triangles and the half sweep over the shards
+        TriArgs t;
+        fill_tri_batch(&t, nullptr, n, d, d, sp.shards);
+        SymSweeps sw;
+        if (!plan_sym_sweeps(&sw, n, device_cus(), 64, true)) return 0;
+        return t.total_tiles + sw.work[0].total_tiles;
+    }
     return tvbf_topk_sym_tiles(n);
 }
 
@@ -4088,7 +4199,7 @@ int tvbf_cosine_topk_sym_f32(const float* Z, int64_t n, int64_t d, int64_t ld, i
                            (hipStream_t)stream, t);
         hipLaunchKernelGGL(matrix_rows_topk_kernel<false>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                            reinterpret_cast<const float*>(workspace), n, sp.ldm, k, min_similarity, exclude_self,
-                           out_idx, out_score, out_count, (int64_t)0, (u64*)nullptr, (u64*)nullptr);
+                           out_idx, out_score, out_count, (int64_t)0, (u64*)nullptr, (u64*)nullptr, 0, 0);
         HIP_TRY(hipGetLastError());
         return TVBF_OK;
     }
@@ -4107,8 +4218,29 @@ int tvbf_cosine_topk_sym_f32(const float* Z, int64_t n, int64_t d, int64_t ld, i
     rc = tvbf_topk_colside_begin(cs.state, cs.state_bytes, n, cs.cap, stream);
     if (rc) return rc;
     int used = 0, used_full = 0;
-    rc = tvbf_topk_accumulate_sym_f32(Z, n, 0, d, ld, k, min_similarity, exclude_self, workspace, sp.topk_bytes, 0,
-                                      sp.s_sym, &used, &cs, stream);
+    if (sp.own_bytes) {
+        // every shard's own block: its triangle into the shard's rows of the matrix, then one scan per
+        // row into list slot 0, which also raises the row's bound -- the bounds the half sweep starts with
+        const float ms = min_similarity < -FLT_MAX ? -FLT_MAX : min_similarity;  // -inf marks columns past the end
+        TriArgs t;
+        fill_tri_batch(&t, Z, n, d, ld, sp.shards);
+        t.out = reinterpret_cast<float*>(ws + sp.off_own);
+        t.ldo = sp.own_ldm;
+        hipLaunchKernelGGL(cosine_tri_dma_kernel<TRI_STORE>, dim3((unsigned)t.items), dim3(TOPK_THREADS), 0,
+                           (hipStream_t)stream, t);
+        hipLaunchKernelGGL(matrix_rows_topk_kernel<true>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const float*>(ws + sp.off_own), n, sp.own_ldm, k, ms, exclude_self,
+                           (int32_t*)nullptr, (float*)nullptr, (int32_t*)nullptr, (int64_t)0,
+                           reinterpret_cast<u64*>(ws + ws_bound_bytes(n)), reinterpret_cast<u64*>(ws), sp.shards,
+                           (int)((n + BM - 1) / BM));
+        HIP_TRY(hipGetLastError());
+        rc = accumulate_sym_impl(Z, n, 0, d, ld, k, min_similarity, exclude_self, workspace, sp.topk_bytes, 1,
+                                 sp.s_sym - 1, &used, &cs, stream, true);
+        used += 1;
+    } else {
+        rc = tvbf_topk_accumulate_sym_f32(Z, n, 0, d, ld, k, min_similarity, exclude_self, workspace, sp.topk_bytes, 0,
+                                          sp.s_sym, &used, &cs, stream);
+    }
     if (rc) return rc;
     rc = accumulate_impl(Z, n, 0, d, ld, Z, n, 0, nullptr, 0, 0, k, min_similarity, exclude_self, workspace,
                          sp.topk_bytes, used, sp.s_full, &used_full, nullptr, flag, stream);
@@ -4150,7 +4282,7 @@ int tvbf_topk_accumulate_matrix_f32(const float* Zq, int64_t nq, int64_t q_row0,
     hipLaunchKernelGGL(matrix_rows_topk_kernel<true>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const float*>(matrix), nq, t.ldo, k, min_similarity, exclude_self,
                        (int32_t*)nullptr, (float*)nullptr, (int32_t*)nullptr, q_row0,
-                       reinterpret_cast<u64*>(ws + ws_bound_bytes(nq)) + (size_t)slot0 * nq * k, reinterpret_cast<u64*>(ws));
+                       reinterpret_cast<u64*>(ws + ws_bound_bytes(nq)) + (size_t)slot0 * nq * k, reinterpret_cast<u64*>(ws), 0, 0);
     HIP_TRY(hipGetLastError());
     *slots_used = 1;
     return TVBF_OK;
