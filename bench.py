@@ -466,8 +466,9 @@ def main():
                      "kernel": ("cosine_topk_dma_kernel<false, 0, false> + <false, 0, true> (own block and half sweep of the "
                                 "symmetric sharded route; HIP events span the collectives between them as well)"
                                 if symmetric and world > 1 else
-                                "cosine_topk_dma_kernel<false, 1> + <false, 2> (own-shard and half sweeps of the symmetric "
-                                "route; HIP events span the whole call: fills, column-buffer reduction, list merge)"
+                                "cosine_topk_dma_kernel<false, 2> (half sweep of the symmetric route) + cosine_tri_dma_kernel<0> "
+                                "(the shards' own blocks); HIP events span the whole call: fills, row selection of the own "
+                                "blocks, column-buffer reduction, list merge"
                                 if symmetric else
                                 "cosine_topk_dma_kernel<false, 0> (HIP events also span the 4 us bound fill and the "
                                 "0.3 ms list merge of the same call)"), "kernel_ms": kernel_avg_ms,

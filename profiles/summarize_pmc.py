@@ -4,8 +4,9 @@ time of profiles/collect_stats.sh (gpurun_out/stats_<tag>/) into the JSON summar
 profiles/:   python profiles/summarize_pmc.py <tag> plain|symmetric|matrix [--round r02 --n .. --d .. --k .. --data ..]
 
 plain:     the general sweep, cosine_topk_dma_kernel<false, 0, false> (bench.py --sweep plain)
-symmetric: the own-columns sweep <false, 1, false> plus the half sweeps <false, 2, true> of one call
-           (bench.py default on one GPU); their counters and times are added up per call.
+symmetric: the half sweep <false, 2, true> plus the shards' own blocks (cosine_tri_dma_kernel<0> with a table of
+           diagonal blocks + matrix_rows_topk_kernel<true>) of one call (bench.py default on one GPU); their
+           counters and times are added up per call.
 matrix:    the stored-matrix route of small catalogues: cosine_tri_dma_kernel<0> + matrix_rows_topk_kernel."""
 import collections
 import csv
@@ -32,7 +33,7 @@ pmc = root / "gpurun_out" / f"pmc_{tag}"
 stats = root / "gpurun_out" / f"stats_{tag}"
 lg = "true" if args.k > 30 else "false"  # lists in global memory above K = 30
 KERNELS = {"plain": [f"cosine_topk_dma_kernel<{lg}, 0, false>"],
-           "symmetric": [f"cosine_topk_dma_kernel<{lg}, 1, false>", f"cosine_topk_dma_kernel<{lg}, 2, true>"],
+           "symmetric": [f"cosine_topk_dma_kernel<{lg}, 2, true>", "cosine_tri_dma_kernel<0>", "matrix_rows_topk_kernel<true>"],
            "matrix": ["cosine_tri_dma_kernel<0>", "matrix_rows_topk_kernel"]}[mode]
 suffix = {"plain": "", "symmetric": "_symmetric", "matrix": "_matrix"}[mode]
 wl = f"n{args.n // 1000}k_d{args.d}_k{args.k}" + ("" if args.data == "hybrid" else f"_{args.data}")

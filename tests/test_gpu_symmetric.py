@@ -211,8 +211,8 @@ def test_symmetric_shape_limits(pkg, device, monkeypatch):
     assert engine.symmetric_workspace_bytes(100_000, 1024, 100) > 0
     # small catalogues: the scores are stored as an n x n matrix (rows padded to 32 floats)
     assert engine.symmetric_workspace_bytes(1900, 64, 5) == 1900 * 1920 * 4
-    assert engine.symmetric_workspace_bytes(36864, 64, 5) == 36864 * 36864 * 4
-    assert 0 < engine.symmetric_workspace_bytes(36865, 64, 5) < 36865 * 36865 * 4  # fused sweeps: lists and column buffers
+    assert engine.symmetric_workspace_bytes(24576, 64, 5) == 24576 * 24576 * 4
+    assert 0 < engine.symmetric_workspace_bytes(24577, 64, 5) < 24577 * 24577 * 4  # fused sweeps: lists, own blocks, column buffers
     assert engine.symmetric_workspace_bytes(1900, 96, 5) == 0
     monkeypatch.setenv("TVBF_SYM_ROUTE", "fused")
     assert engine.symmetric_workspace_bytes(1900, 64, 5) == 0             # fewer than 16 blocks of 128 shows

@@ -4041,16 +4041,17 @@ static size_t sym_own_matrix_bytes(int64_t n, int shards, int64_t* ldm) {
     return bytes <= OWN_MATRIX_MAX_BYTES ? bytes : 0;
 }
 
-// Catalogues up to this many shows take the matrix route (n^2 floats: 5.4 GB at the limit).  Below
+// Catalogues up to this many shows take the matrix route (n^2 floats: 2.4 GB at the limit).  Below
 // a few thousand columns per list the fused epilogue spends more time on cold lists than the
 // matrix pipe spends on the products; storing and scanning n^2 floats costs 8 n^2 bytes of
 // traffic instead, which at these sizes is the smaller price (measured at D = 512: 0.64 against
-// 1.25 ms at n = 10,000, 1.56 against 2.12 ms at 16,384, 3.04 against 3.66 ms at 24,000; at
-// D = 576: 4.47 against 4.72 ms at 30,000, 6.32 against 6.59 ms at 36,000, 9.44 against 9.25 ms
-// at 44,000 -- the fused sweeps win from about 40,000 shows on, and their workspace grows with n,
-// not n^2).
+// 1.25 ms at n = 10,000, 1.56 against 2.12 ms at 16,384, 3.04 against 3.66 ms at 24,000 with
+// fused own-block sweeps; with the shards' own blocks stored as well -- see sym_own_matrix_bytes --
+// the two routes tie between 20,000 and 30,000 shows, D = 576: 2.15 against 2.17 ms at 20,000,
+// 3.44 against 3.45 at 26,000, 4.47 against 4.45 at 30,000, 6.31 against 6.14 at 36,000; the fused
+// route's workspace grows with n, not n^2).
 // TVBF_SYM_ROUTE=fused|matrix overrides (test / tuning aid; matrix up to 65,536).
-constexpr int64_t MATRIX_ROUTE_MAX_N = 36864;
+constexpr int64_t MATRIX_ROUTE_MAX_N = 24576;
 constexpr int64_t MATRIX_ROUTE_HARD_MAX_N = 65536;
 
 static bool sym_route_matrix(int64_t n, int64_t d) {
