@@ -215,10 +215,7 @@ __global__ __launch_bounds__(256) void normalize_blocks_kernel(const float* __re
 // ds_read_b128 lane group then fall on sixteen different 16-byte bank slots.
 // --------------------------------------------------------------------------
 constexpr int BM = 128;
-#ifndef TVBF_BN
-#define TVBF_BN 128
-#endif
-constexpr int BN = TVBF_BN;  // column shows per tile
+constexpr int BN = 128;  // column shows per tile
 constexpr int NJ = BN / 32;  // 32x32 MFMA sub-tiles per wave and tile
 constexpr int BK = 32;
 constexpr int LDT = BK + 4;
@@ -3161,9 +3158,6 @@ static int topk_cap(int k, int64_t d) {
         const int v = atoi(e);
         if (v >= 4 && v <= 64 && (topk_list_global(k) || v >= k + 2)) return v;
     }
-#if TVBF_BN == 256
-    if (k <= 20) return 24;  // keeps two workgroups per CU with the wider column tile
-#endif
     if (topk_list_global(k)) return 32;
     if (topk_use_dma(d)) return k + 12 < 38 ? k + 12 : 38;  // 32 KiB of tiles + 8 KiB of scratch beside the lists
     if (k <= 30) return k + 12;
