@@ -150,6 +150,37 @@ def test_symmetric_dense_against_oracle(pkg, device, monkeypatch, n, d, k):
                               what=f"symmetric dense {n}x{d} k={k}")
 
 
+@pytest.mark.parametrize("n,shards,k,ms,self_too", [
+    (2100, 16, 20, 0.1, False),    # 17 row blocks, 16 shards: blocks of one and two row blocks, ragged last one
+    (1999, 15, 100, -1.0, False),  # lists in global memory, threshold off: every score of a block is a candidate
+    (3333, 3, 7, 0.3, True),       # large blocks, the show itself kept
+    (4097, 32, 31, 0.05, False),   # one row in the last row block
+])
+def test_own_blocks_as_a_batch_of_matrices(pkg, device, monkeypatch, n, shards, k, ms, self_too):
+    """The shards' own blocks through the batched triangle kernel and the row selection (the default
+    of the whole-catalogue call): lists equal to the plain sweep and to the fused own-block sweeps,
+    and the workspace holds the blocks' matrices."""
+    import torch
+
+    from tvbingefriend_recommendation_service_amd import engine
+
+    monkeypatch.setenv("TVBF_SYM_SHARDS", str(shards))
+    monkeypatch.setenv("TVBF_SYM_ROUTE", "fused")
+    z, _, _ = _z_hybrid(device, n, seed=4000 + n)
+    ld = z.shape[1]
+    plain = engine.cosine_topk(z, k, ms, exclude_self=not self_too)
+    results = {}
+    for own in ("matrix", "fused"):
+        monkeypatch.setenv("TVBF_SYM_OWN", own)
+        results[own] = (_sym(z, k, ms, expect_overflow=None, exclude_self=not self_too),
+                        engine.symmetric_workspace_bytes(n, ld, k))
+    torch.cuda.synchronize()
+    _assert_same(results["matrix"][0], plain, f"own blocks stored, n={n} shards={shards} k={k}")
+    _assert_same(results["fused"][0], plain, f"own blocks fused, n={n} shards={shards} k={k}")
+    widest = max((v + 1) * ((n + 127) // 128) // shards - v * ((n + 127) // 128) // shards for v in range(shards))
+    assert results["matrix"][1] > n * widest * 128 * 4  # the workspace holds the blocks' matrices
+
+
 def test_symmetric_keeps_self_when_asked(pkg, device, monkeypatch):
     import torch
 
