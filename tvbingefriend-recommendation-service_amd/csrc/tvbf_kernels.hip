@@ -3325,15 +3325,15 @@ struct SymSweeps {
     int sweep_slots;                   // sum of slots[]
 };
 
-// own_done: the shards' own blocks are dealt with elsewhere (stored as matrices); only the half
-// sweep over the shards is planned.
-static bool plan_sym_sweeps(SymSweeps* sw, int64_t nq, int cus, int budget, bool own_done = false) {
+// own_shards > 0: the own blocks of that many shards are dealt with elsewhere (stored as
+// matrices); only the half sweep over those shards is planned.
+static bool plan_sym_sweeps(SymSweeps* sw, int64_t nq, int cus, int budget, int own_shards = 0) {
     const int row_blocks = (int)((nq + BM - 1) / BM);
-    const int shards = sym_shards(row_blocks);
+    const int shards = own_shards > 0 ? own_shards : sym_shards(row_blocks);
     if (shards < 2) return false;
     const int ring = sym_ring(row_blocks, shards);
     memset(sw, 0, sizeof(*sw));
-    if (own_done) {
+    if (own_shards > 0) {
         sw->n = 1;
         sw->sym[0] = SYM_HALF, sw->shards[0] = shards, sw->ring[0] = shards;
     } else if (ring > 1) {
@@ -3685,12 +3685,13 @@ int tvbf_topk_accumulate_ex_f32(const float* Zq, int64_t nq, int64_t q_row0, int
 // The symmetric sweep of a block of rows against itself inside an incremental sequence: the
 // own-columns sweep, the half sweep (column side into the caller's column-side state, at the
 // block's global rows) and the reduction of those buffers into one more list slot.
-// own_done: every shard's own block (its rows against its own columns) has already been written
-// to a list slot below slot0 and has raised the bounds; only the half sweep over the shards runs.
+// own_shards > 0: the own block of each of that many shards (its rows against its own columns) has
+// already been written to a list slot below slot0 and has raised the bounds; only the half sweep
+// over those shards runs.
 static int accumulate_sym_impl(const float* Zq, int64_t nq, int64_t q_row0, int64_t d, int64_t ld, int k,
                                float min_similarity, int exclude_self, void* workspace, size_t workspace_bytes,
                                int slot0, int max_slots, int* slots_used, const tvbf_colside* colside,
-                               void* stream, bool own_done) {
+                               void* stream, int own_shards) {
     if (!slots_used) return fail(TVBF_E_BAD_ARG, "slots_used must be non-null");
     *slots_used = 0;
     if (!colside) return fail(TVBF_E_BAD_ARG, "the symmetric sweep needs a column-side state");
@@ -3713,7 +3714,7 @@ static int accumulate_sym_impl(const float* Zq, int64_t nq, int64_t q_row0, int6
     const int budget = max_slots - 1;  // one slot is the reduced column side
     if (budget < 2) return fail(TVBF_E_BAD_ARG, "the symmetric sweep needs at least 3 slots");
     SymSweeps sw;
-    if (!col_lds || !plan_sym_sweeps(&sw, nq, cus, budget, own_done))
+    if (!col_lds || !plan_sym_sweeps(&sw, nq, cus, budget, own_shards))
         return fail(TVBF_E_BAD_SHAPE, "the symmetric sweep needs d %% 64 == 0 and at least 16 row blocks");
     const size_t lds_diag = topk_lds_bytes(k, d);
     const int total = sw.sweep_slots + 1;
@@ -3801,7 +3802,7 @@ int tvbf_topk_accumulate_sym_f32(const float* Zq, int64_t nq, int64_t q_row0, in
                                  int slot0, int max_slots, int* slots_used, const tvbf_colside* colside,
                                  void* stream) {
     return accumulate_sym_impl(Zq, nq, q_row0, d, ld, k, min_similarity, exclude_self, workspace, workspace_bytes, slot0,
-                               max_slots, slots_used, colside, stream, false);
+                               max_slots, slots_used, colside, stream, 0);
 }
 
 size_t tvbf_topk_colside_bytes(int64_t n_total, int cap) {
@@ -4079,8 +4080,16 @@ static SymPlan make_sym_plan(int64_t n, int64_t d, int k) {
     SymSweeps sw;
     sp.shards = shards;
     sp.own_bytes = sym_own_matrix_bytes(n, shards, &sp.own_ldm);
+    if (sp.own_bytes && topk_list_global(k) && shards > 8 && !getenv("TVBF_SYM_SHARDS")) {
+        // Long lists (kept in global memory) make the fused sweep's selection dearer, the stored
+        // blocks' hardly: eight larger blocks when their matrices fit (K = 50: 0.4 ... 2.8 % of a
+        // call between 100,000 x 2048 and 50,000 x 1024; no difference at K = 20)
+        int64_t ldm8 = 0;
+        const size_t bytes8 = sym_own_matrix_bytes(n, 8, &ldm8);
+        if (bytes8) sp.shards = 8, sp.own_bytes = bytes8, sp.own_ldm = ldm8;
+    }
     if (sp.own_bytes) {  // one slot for the own blocks, the half sweep's, one for the reduced column side
-        if (!plan_sym_sweeps(&sw, n, cus, slots - 2, true)) return sp;
+        if (!plan_sym_sweeps(&sw, n, cus, slots - 2, sp.shards)) return sp;
         sp.s_sym = sw.sweep_slots + 2;
     } else {
         if (!plan_sym_sweeps(&sw, n, cus, slots - 1)) return sp;
@@ -4157,7 +4166,7 @@ int64_t tvbf_cosine_topk_sym_tiles(int64_t n, int64_t d, int k) {
         TriArgs t;
         fill_tri_batch(&t, nullptr, n, d, d, sp.shards);
         SymSweeps sw;
-        if (!plan_sym_sweeps(&sw, n, device_cus(), 64, true)) return 0;
+        if (!plan_sym_sweeps(&sw, n, device_cus(), 64, sp.shards)) return 0;
         return t.total_tiles + sw.work[0].total_tiles;
     }
     return tvbf_topk_sym_tiles(n);
@@ -4230,7 +4239,7 @@ int tvbf_cosine_topk_sym_f32(const float* Z, int64_t n, int64_t d, int64_t ld, i
                            (int)((n + BM - 1) / BM));
         HIP_TRY(hipGetLastError());
         rc = accumulate_sym_impl(Z, n, 0, d, ld, k, min_similarity, exclude_self, workspace, sp.topk_bytes, 1,
-                                 sp.s_sym - 1, &used, &cs, stream, true);
+                                 sp.s_sym - 1, &used, &cs, stream, sp.shards);
         used += 1;
     } else {
         rc = tvbf_topk_accumulate_sym_f32(Z, n, 0, d, ld, k, min_similarity, exclude_self, workspace, sp.topk_bytes, 0,
