@@ -186,7 +186,7 @@ int tvbf_cosine_topk_static_f32(const float* Zq, int64_t nq, int64_t q_row0, con
  * stored matrix of this size is cheaper.  Larger catalogues take the fused sweeps described
  * below, which need at least 16 blocks of 128 rows.
  * They keep, besides the lists, the scores of every shard's own block (n x about n / 32 floats,
- * n / 8 for k > 30, while that is at most 8 GiB) in the workspace: those blocks are computed as stored matrices too.
+ * up to n / 4 for k > 30, while that is at most 8 GiB) in the workspace: those blocks are computed as stored matrices too.
  * Every show has a buffer of 1024 column-side candidates (2048 for k > 64); should one overflow, the show is
  * flagged and a plain sweep restricted to the 128-row blocks that hold flagged shows recomputes
  * their lists on the device, without host synchronisation (it returns at once when nothing is

@@ -4080,13 +4080,19 @@ static SymPlan make_sym_plan(int64_t n, int64_t d, int k) {
     SymSweeps sw;
     sp.shards = shards;
     sp.own_bytes = sym_own_matrix_bytes(n, shards, &sp.own_ldm);
-    if (sp.own_bytes && topk_list_global(k) && shards > 8 && !getenv("TVBF_SYM_SHARDS")) {
+    if (sp.own_bytes && topk_list_global(k) && !getenv("TVBF_SYM_SHARDS") && !getenv("TVBF_SYM_OWN")) {
         // Long lists (kept in global memory) make the fused sweep's selection dearer, the stored
-        // blocks' hardly: eight larger blocks when their matrices fit (K = 50: 0.4 ... 2.8 % of a
-        // call between 100,000 x 2048 and 50,000 x 1024; no difference at K = 20)
-        int64_t ldm8 = 0;
-        const size_t bytes8 = sym_own_matrix_bytes(n, 8, &ldm8);
-        if (bytes8) sp.shards = 8, sp.own_bytes = bytes8, sp.own_ldm = ldm8;
+        // blocks' hardly: fewer, larger blocks -- 4, 8 or 16 -- as far as their matrices fit (K = 50:
+        // 8 instead of 32 blocks save 0.4 ... 2.8 % of a call between 100,000 x 2048 and 50,000 x
+        // 1024, 4 blocks another 1.8 % at 50,000; no difference at K = 20)
+        for (int fewer = 4; fewer < shards; fewer *= 2) {
+            int64_t ldm_f = 0;
+            const size_t bytes_f = sym_own_matrix_bytes(n, fewer, &ldm_f);
+            if (bytes_f) {
+                sp.shards = fewer, sp.own_bytes = bytes_f, sp.own_ldm = ldm_f;
+                break;
+            }
+        }
     }
     if (sp.own_bytes) {  // one slot for the own blocks, the half sweep's, one for the reduced column side
         if (!plan_sym_sweeps(&sw, n, cus, slots - 2, sp.shards)) return sp;
