@@ -179,7 +179,7 @@ int tvbf_cosine_topk_static_f32(const float* Zq, int64_t nq, int64_t q_row0, con
  *   d           multiple of 64
  *   workspace   >= tvbf_cosine_topk_sym_workspace_bytes(n, d, k) bytes, which returns 0 when
  *               the shape is not taken (call tvbf_cosine_topk_f32 then)
- * Catalogues of up to 24,576 shows take a second route with the same result: the tiles on and
+ * Catalogues of up to 24,576 shows (46,336 for k > 30) take a second route with the same result: the tiles on and
  * above the diagonal are computed once and stored, with their transposes, as a dense n x n fp32
  * matrix in the workspace (4 n^2 bytes), and one pass per row selects its list.  Short sweeps
  * spend most of their time on lists that have not seen enough columns to reject anything; a

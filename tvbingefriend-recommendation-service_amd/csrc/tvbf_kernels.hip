@@ -4049,21 +4049,27 @@ static size_t sym_own_matrix_bytes(int64_t n, int shards, int64_t* ldm) {
 constexpr int64_t MATRIX_ROUTE_MAX_N = 24576;
 constexpr int64_t MATRIX_ROUTE_HARD_MAX_N = 65536;
 
-static bool sym_route_matrix(int64_t n, int64_t d) {
+// Long lists (K > 30: kept in global memory by the fused sweeps, whose selection then costs more;
+// the row scan of a stored matrix hardly notices K) take the matrix route up to this many shows
+// (8.6 GB; K = 50 at D = 576: 3.48 against 3.71 ms at 26,000, 7.83 against 8.13 at 40,000, 10.28
+// against 10.48 at 46,000; K = 100 at 46,000 x 1024: 16.9 against 18.2 ms).
+constexpr int64_t MATRIX_ROUTE_MAX_N_LONG_LISTS = 46336;
+
+static bool sym_route_matrix(int64_t n, int64_t d, int k) {
     if (!topk_use_dma(d) || n > MATRIX_ROUTE_HARD_MAX_N) return false;
     if (const char* e = getenv("TVBF_SYM_ROUTE")) {
         if (!strcmp(e, "fused")) return false;
         if (!strcmp(e, "matrix")) return true;
     }
     if (getenv("TVBF_SYM_SHARDS") || getenv("TVBF_SYM_RING")) return false;  // shard overrides address the fused sweeps
-    return n <= MATRIX_ROUTE_MAX_N;
+    return n <= (topk_list_global(k) ? MATRIX_ROUTE_MAX_N_LONG_LISTS : MATRIX_ROUTE_MAX_N);
 }
 
 static SymPlan make_sym_plan(int64_t n, int64_t d, int k) {
     SymPlan sp;
     memset(&sp, 0, sizeof(sp));
     if (n < 1 || k < 1 || k > TVBF_MAX_K) return sp;
-    if (sym_route_matrix(n, d)) {
+    if (sym_route_matrix(n, d, k)) {
         sp.matrix = true;
         sp.ldm = (n + 31) / 32 * 32;  // rows start on 128-byte boundaries
         sp.bytes = (size_t)n * (size_t)sp.ldm * sizeof(float);
