@@ -244,6 +244,9 @@ def test_symmetric_shape_limits(pkg, device, monkeypatch):
     assert engine.symmetric_workspace_bytes(1900, 64, 5) == 1900 * 1920 * 4
     assert engine.symmetric_workspace_bytes(24576, 64, 5) == 24576 * 24576 * 4
     assert 0 < engine.symmetric_workspace_bytes(24577, 64, 5) < 24577 * 24577 * 4  # fused sweeps: lists, own blocks, column buffers
+    # long lists (kept in global memory by the fused sweeps) take the matrix route further up
+    assert engine.symmetric_workspace_bytes(46336, 64, 50) == 46336 * 46336 * 4
+    assert 0 < engine.symmetric_workspace_bytes(46337, 64, 50) < 46337 * 46337 * 4
     assert engine.symmetric_workspace_bytes(1900, 96, 5) == 0
     monkeypatch.setenv("TVBF_SYM_ROUTE", "fused")
     assert engine.symmetric_workspace_bytes(1900, 64, 5) == 0             # fewer than 16 blocks of 128 shows
