@@ -105,16 +105,23 @@ def neighbour_table(result: TopKResult, show_ids) -> dict:
     for ``executemany`` / bulk loaders.  No Python object per pair is created."""
     ids = np.asarray(show_ids)
     k = result.idx.shape[1]
-    keep = np.arange(k)[None, :] < np.asarray(result.count)[:, None]
-    rows, slots = np.nonzero(keep)  # row-major: shows ascending, ranks ascending
-    comp = np.asarray(result.comp)
+    count = np.asarray(result.count)
+    # flat masks over the (show, rank) grid, row-major: shows ascending, ranks ascending
+    keep = (np.arange(k)[None, :] < count[:, None]).reshape(-1)
+    whole = bool(keep.all())  # every list full: the grid IS the table
+
+    def kept(a, width=None):
+        flat = np.asarray(a).reshape(-1) if width is None else np.asarray(a).reshape(-1, width)
+        return flat if whole else flat[keep]
+
+    comp = kept(result.comp, 3)
     return {
-        "show_id": ids[rows],
-        "similar_show_id": ids[np.asarray(result.idx)[rows, slots]],
-        "similarity_score": np.asarray(result.score, dtype=np.float64)[rows, slots],
-        "genre_score": comp[rows, slots, 0].astype(np.float64),
-        "text_score": comp[rows, slots, 1].astype(np.float64),
-        "metadata_score": comp[rows, slots, 2].astype(np.float64),
+        "show_id": np.repeat(ids, np.minimum(count, k)),
+        "similar_show_id": ids[kept(result.idx)],
+        "similarity_score": kept(result.score).astype(np.float64),
+        "genre_score": comp[:, 0].astype(np.float64),
+        "text_score": comp[:, 1].astype(np.float64),
+        "metadata_score": comp[:, 2].astype(np.float64),
     }
 
 
