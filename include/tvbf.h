@@ -374,6 +374,53 @@ int tvbf_refine_min_similarity_f64(int32_t* idx, float* score, int32_t* count, f
                                    double min_similarity, double band, void* stream);
 
 /*
+ * Float64 re-rank: the order, the scores and the threshold cut of the reference's float64
+ * arithmetic for the candidates an fp32 sweep returned.  Replaces, for every show, the float64
+ * score row of scripts/populate_database.py:180-192 (ml/similarity_computer.py:122-124), the
+ * argsort of :195, the walk of :198-218 and the component look-ups of :214-216 -- restricted to
+ * the show's candidates, whose float64 scores are computed from the stored feature arrays
+ * themselves (the sources of tvbf_assemble_normalize_f32; sources must not overlap here).
+ *
+ *   tvbf_block_norms_f64    norms[i * nb + b] = float64 L2 norm of block b of show i, a norm below
+ *                           10 * DBL_EPSILON replaced by 1 (sklearn's normalize).  finite_flag
+ *                           (device int32, optional, zeroed by the caller): bit 0 is set when a
+ *                           stored value is NaN, bit 1 when one is infinite -- the inputs sklearn's
+ *                           check_pairwise_arrays rejects (ml/similarity_computer.py:41,58,86).
+ *   tvbf_rescore_topk_f64   query r is show row_ids[r] (device int32) or, with row_ids == NULL,
+ *                           show q_row0 + r; its candidates are cand_idx[r, 0..cand_count[r])
+ *                           (kc per row, -1 = unused; cand_score: their fp32 scores, descending --
+ *                           the outputs of tvbf_cosine_topk_f32 with k = kc).  For every candidate j
+ *                               c_b = <x_i, x_j>_b / (|x_i|_b |x_j|_b)       per feature block b
+ *                               comp_g = mean of c_b over the blocks of group g (block_group[b] in 0..2)
+ *                               h = (w[0] * comp_0 + w[1] * comp_1) + w[2] * comp_2    (no fused multiply-add)
+ *                           candidates with h >= min_similarity are ordered by (h descending, column
+ *                           ascending) and the first k written to row (row_ids ? row_ids[r] - out_row0 : r)
+ *                           of out_idx (x k, -1 padded), out_score (x k float64), out_comp (x k x 3),
+ *                           out_count.  The show itself is skipped when exclude_self.
+ *                           flagged (device int32, 1 + nq entries, [0] zeroed by the caller; may be
+ *                           NULL): a show outside a FULL candidate list has an fp32 score of at most
+ *                           the list's last, hence a float64 score below last + margin; when that
+ *                           could still reach min_similarity and the k-th float64 score found, the
+ *                           show's index is appended ([0] counts them, order unspecified): fetch a
+ *                           longer candidate list for those shows, or score them against all shows:
+ *   tvbf_score_rows_f64     H[r, j] = h of show row_ids[r] against every show j (-inf at the show
+ *                           itself when exclude_self); tvbf_dense_rows_topk_f64 selects from H.
+ * d <= 16384; kc <= 1024 (d * 8 + kc * 36 bytes of LDS).  No counterpart in the reference beyond the lines cited (it ranks full
+ * float64 rows).
+ */
+int tvbf_block_norms_f64(const tvbf_source* sources, int ns, int64_t n, int64_t d, const int32_t* block_offsets,
+                         int nb, double* norms, int32_t* finite_flag, void* stream);
+int tvbf_rescore_topk_f64(const tvbf_source* sources, int ns, int64_t n, int64_t d, const int32_t* block_offsets,
+                          int nb, const int32_t* block_group, const double* group_weight, const double* norms,
+                          const int32_t* row_ids, int64_t nq, int64_t q_row0, const int32_t* cand_idx,
+                          const float* cand_score, const int32_t* cand_count, int kc, int k, double min_similarity,
+                          double margin, int exclude_self, int32_t* out_idx, double* out_score, double* out_comp,
+                          int32_t* out_count, int64_t out_row0, int32_t* flagged, void* stream);
+int tvbf_score_rows_f64(const tvbf_source* sources, int ns, int64_t n, int64_t d, const int32_t* block_offsets,
+                        int nb, const int32_t* block_group, const double* group_weight, const double* norms,
+                        const int32_t* row_ids, int64_t nr, int exclude_self, double* H, int64_t ldh, void* stream);
+
+/*
  * K3 -- weighted hybrid sum of three score matrices (any equal-sized buffers):
  * out[i] = (wa*a[i] + wb*b[i]) + wc*c[i] in float64, each product and sum
  * rounded separately, which is bit-for-bit the NumPy expression of

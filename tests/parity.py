@@ -23,15 +23,25 @@ import numpy as np
 
 SCORE_TOL = 1e-5
 GAP_TOL = 2e-6
+# Refined mode -- results of the float64 re-rank (engine.exact_topk, SimilarityComputer.topk):
+# scores within REFINED_TOL of the oracle's float64 scores and indices exactly the oracle's at every
+# rank whose float64 score differs from both neighbouring ranks by more than REFINED_GAP.  What is
+# left out are exact float64 ties (and pairs of scores a few units in the last place apart, whose
+# order depends on the summation order of the BLAS that computed them): there the reference's own
+# order comes from an unstable argsort.  Counts must equal the oracle's where no score lies within
+# REFINED_TOL of the threshold.
+REFINED_TOL = 1e-12
+REFINED_GAP = 1e-12
 
 
 def check_topk_against_scores(h_rows, row0, k, min_similarity, got_idx, got_score, got_count,
                               exclude_self=True, tol=SCORE_TOL, what="", check_tie_order=True, gap=GAP_TOL,
-                              stats=None):
+                              stats=None, f64=False):
     """``h_rows`` holds the oracle's full float64 score rows for the query rows.
     ``check_tie_order`` also demands index order among scores that are equal in fp32
     (the kernels' rule; a float64 stand-in cannot be held to it).  ``stats`` (a dict) collects
     ``ranks`` compared, ``exact`` (ranks held to index equality) and ``max_err`` (largest score error).
+    ``f64``: the result's scores are float64 (their own order is checked as float64).
     Returns the number of ranks held to (and meeting) index equality."""
     h_rows = np.asarray(h_rows, dtype=np.float64)
     nq, n = h_rows.shape
@@ -65,7 +75,7 @@ def check_topk_against_scores(h_rows, row0, k, min_similarity, got_idx, got_scor
         assert np.all(np.abs(gs - srt[:c]) <= tol), (
             f"{what} row {r}: rank-wise score mismatch {np.abs(gs - srt[:c]).max():.3e}")
         # order of the result itself
-        d = np.diff(gs.astype(np.float32))
+        d = np.diff(gs if f64 else gs.astype(np.float32))
         assert np.all(d <= 0), f"{what} row {r}: scores not descending"
         same = d == 0
         if check_tie_order:

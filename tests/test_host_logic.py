@@ -545,3 +545,23 @@ def test_record_dicts_built_in_c_equal_the_python_loop(pkg):
     bad.idx[np.nonzero(count)[0][0], 0] = n + 5
     with pytest.raises(ValueError):
         pd_.neighbour_records(bad, ids, 0, n)
+
+
+def test_catalogue_route_is_bounded_by_available_memory():
+    """engine.choose_catalogue_route: the symmetric call's workspace (score matrices, column-side
+    buffers) is taken only while it fits into the available memory; the plain sweep gives the same
+    lists with a small workspace."""
+    import tvbf_amd  # noqa: F401
+    from tvbingefriend_recommendation_service_amd import engine
+
+    gib = 1 << 30
+    assert engine.choose_catalogue_route(2 * gib, 50 << 20, 100 * gib) == "symmetric"
+    assert engine.choose_catalogue_route(9 * gib, 50 << 20, 8 * gib) == "plain"          # does not fit
+    assert engine.choose_catalogue_route(int(7.5 * gib), 50 << 20, 8 * gib) == "plain"   # inside the headroom
+    assert engine.choose_catalogue_route(0, 50 << 20, 100 * gib) == "plain"              # shape not taken
+    assert engine.choose_catalogue_route(2 * gib, 50 << 20, 100 * gib, "plain") == "plain"
+    assert engine.choose_catalogue_route(9 * gib, 50 << 20, 8 * gib, "symmetric") == "symmetric"  # forced
+    with pytest.raises(MemoryError):
+        engine.choose_catalogue_route(9 * gib, 2 * gib, 1 * gib)
+    assert engine.candidate_count(20) == 28 and engine.candidate_count(22) == 30
+    assert engine.candidate_count(23) == 39 and engine.candidate_count(90) == 100 and engine.candidate_count(100) == 100

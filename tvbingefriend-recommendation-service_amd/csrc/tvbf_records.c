@@ -13,7 +13,7 @@
  *   records(ids, idx, score, comp, count, k, start, stop) -> dict
  *     ids    bytes-like, int64[*]      show id of every row of the catalogue
  *     idx    bytes-like, int32[n][k]   neighbour rows, -1 in unused slots
- *     score  bytes-like, float32[n][k]
+ *     score  bytes-like, float64[n][k]
  *     comp   bytes-like, float64[n][k][3]  genre / text / metadata
  *     count  bytes-like, int32[n]      neighbours kept per row
  *   rows start <= r < stop with count[r] > 0 appear in the result, keyed by ids[r].
@@ -42,7 +42,7 @@ static PyObject* records(PyObject* self, PyObject* args) {
     n = count.len / (Py_ssize_t)sizeof(int32_t);
     n_ids = ids.len / (Py_ssize_t)sizeof(int64_t);
     if (k < 1 || start < 0 || stop > n || idx.len != n * k * (Py_ssize_t)sizeof(int32_t) ||
-        score.len != n * k * (Py_ssize_t)sizeof(float) || comp.len != n * k * 3 * (Py_ssize_t)sizeof(double) || n_ids < stop) {
+        score.len != n * k * (Py_ssize_t)sizeof(double) || comp.len != n * k * 3 * (Py_ssize_t)sizeof(double) || n_ids < stop) {
         PyErr_SetString(PyExc_ValueError, "records(): array sizes do not fit n, k, start, stop");
         goto done;
     }
@@ -52,7 +52,7 @@ static PyObject* records(PyObject* self, PyObject* args) {
     {
         const int64_t* id = (const int64_t*)ids.buf;
         const int32_t* ix = (const int32_t*)idx.buf;
-        const float* sc = (const float*)score.buf;
+        const double* sc = (const double*)score.buf;
         const double* cp = (const double*)comp.buf;
         const int32_t* cn = (const int32_t*)count.buf;
         for (r = start; r < stop && !failed; ++r) {
@@ -74,7 +74,7 @@ static PyObject* records(PyObject* self, PyObject* args) {
                     break;
                 }
                 if (set_steal(d, k_sid, PyLong_FromLongLong((long long)id[j])) ||
-                    set_steal(d, k_sim, PyFloat_FromDouble((double)sc[r * k + s])) ||
+                    set_steal(d, k_sim, PyFloat_FromDouble(sc[r * k + s])) ||
                     set_steal(d, k_genre, PyFloat_FromDouble(p[0])) ||
                     set_steal(d, k_text, PyFloat_FromDouble(p[1])) ||
                     set_steal(d, k_meta, PyFloat_FromDouble(p[2]))) {

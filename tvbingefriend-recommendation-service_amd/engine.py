@@ -91,14 +91,30 @@ _DENSE_KINDS = {torch.float32: native.SRC_DENSE_F32, torch.float64: native.SRC_D
                 torch.uint8: native.SRC_DENSE_U8}
 
 
-def assemble_normalize(sources, n: int, offsets, scales, out: torch.Tensor | None = None) -> torch.Tensor:
-    """Z (n, ld) from feature blocks that are already on the device in their stored form
-    (dense arrays and CSR triples), normalised and weighted block-wise like
-    :func:`normalize_blocks`; no dense copy of a sparse block is ever made."""
+def upload_sources(sources, device) -> list:
+    """The host-side sources of :func:`features.block_sources` (("dense", array, z_col) /
+    ("csr", indptr, indices, data, width, z_col)) as device sources, arrays uploaded as stored."""
+    out = []
+    for src in sources:
+        if src[0] == "dense":
+            out.append(DenseSource(torch.from_numpy(src[1]).to(device), src[2]))
+        else:
+            _, indptr, indices, data, width, z_col = src
+            out.append(CsrSource(torch.from_numpy(indptr).to(device), torch.from_numpy(indices).to(device),
+                                 torch.from_numpy(data).to(device), width, z_col))
+    return out
+
+
+def sources_rows(sources) -> int:
+    """Number of shows the device sources describe."""
+    s = sources[0]
+    return int(s.data.shape[0]) if isinstance(s, DenseSource) else int(s.indptr.numel()) - 1
+
+
+def _source_array(sources, n: int):
+    """ctypes array of struct tvbf_source for device sources of n rows, and their device."""
     if not 1 <= len(sources) <= native.TVBF_MAX_SOURCES:
         raise ValueError(f"1..{native.TVBF_MAX_SOURCES} sources are supported")
-    d = int(offsets[-1])
-    ld = padded_ld(d)
     arr = (native.Source * len(sources))()
     device = None
     for i, s in enumerate(sources):
@@ -129,6 +145,16 @@ def assemble_normalize(sources, n: int, offsets, scales, out: torch.Tensor | Non
             device = s.indptr.device
         else:
             raise TypeError("sources must be DenseSource or CsrSource")
+    return arr, device
+
+
+def assemble_normalize(sources, n: int, offsets, scales, out: torch.Tensor | None = None) -> torch.Tensor:
+    """Z (n, ld) from feature blocks that are already on the device in their stored form
+    (dense arrays and CSR triples), normalised and weighted block-wise like
+    :func:`normalize_blocks`; no dense copy of a sparse block is ever made."""
+    d = int(offsets[-1])
+    ld = padded_ld(d)
+    arr, device = _source_array(sources, n)
     if out is None:
         out = torch.empty((n, ld), dtype=torch.float32, device=device)
     _require_cuda(out, "out")
@@ -280,17 +306,47 @@ def symmetric_inspect(workspace: torch.Tensor, n: int, ld: int, k: int) -> dict:
     return {"overflowed": int(out[0]), "appended": int(out[1]), "max_per_show": int(out[2]), "busiest_show": int(out[3])}
 
 
+MEMORY_HEADROOM = 0.9  # share of the currently available device memory a workspace may take
+
+
+def available_bytes(device) -> int:
+    """Device memory a new torch allocation can use right now: what the driver reports free plus
+    what torch's caching allocator holds without using it."""
+    free, _ = torch.cuda.mem_get_info(device)
+    return int(free) + int(torch.cuda.memory_reserved(device)) - int(torch.cuda.memory_allocated(device))
+
+
+def choose_catalogue_route(symmetric_bytes: int, plain_bytes: int, available: int, choice: str = "auto") -> str:
+    """Which whole-catalogue call to make: "symmetric" (every pair once; its workspace holds score
+    matrices of up to 4 n^2 bytes for a small catalogue, the shards' own blocks -- up to 8 GiB -- and
+    8 KB of column-side buffers per show for a large one) while that workspace fits into
+    ``MEMORY_HEADROOM`` of the available memory, else "plain" (tens of MB).  Both give the same
+    lists bit for bit, so falling back costs time only.  ``choice`` "plain" / "symmetric" forces a
+    route (TVBF_SWEEP)."""
+    if choice == "plain" or symmetric_bytes <= 0:
+        return "plain"
+    if choice == "symmetric" or symmetric_bytes <= MEMORY_HEADROOM * available:
+        return "symmetric"
+    if plain_bytes > MEMORY_HEADROOM * available:
+        raise MemoryError(f"the top-K sweep needs {plain_bytes} bytes of workspace, {available} are available")
+    return "plain"
+
+
 def catalogue_topk(z: torch.Tensor, k: int, min_similarity: float, *, n: int | None = None,
                    exclude_self: bool = True) -> TopK:
     """Top-k of every show against the whole catalogue: the symmetric call when the library takes
     the shape (row length a multiple of 64; it stores the scores of a small catalogue as a matrix
-    and runs the fused symmetric sweeps on a large one), the plain sweep otherwise.  All routes give
-    the same lists bit for bit.  TVBF_SWEEP=plain forces the plain sweep."""
+    and runs the fused symmetric sweeps on a large one) and its workspace fits into the memory that
+    is available, the plain sweep otherwise.  All routes give the same lists bit for bit.
+    TVBF_SWEEP=plain|symmetric forces one."""
     import os
 
     n = z.shape[0] if n is None else int(n)
-    choice = os.environ.get("TVBF_SWEEP", "auto")
-    if choice != "plain" and symmetric_workspace_bytes(n, z.shape[1], k) > 0:
+    with torch.cuda.device(z.device):
+        sym = symmetric_workspace_bytes(n, z.shape[1], k)
+        plain = int(native.load().tvbf_topk_workspace_bytes(n, n, z.shape[1], k))
+    route = choose_catalogue_route(sym, plain, available_bytes(z.device), os.environ.get("TVBF_SWEEP", "auto"))
+    if route == "symmetric":
         return cosine_topk_symmetric(z, k, min_similarity, n=n, exclude_self=exclude_self)
     return cosine_topk(z, k, min_similarity, n=n, exclude_self=exclude_self)
 
@@ -350,6 +406,195 @@ def refine_min_similarity(top: TopK, comp: torch.Tensor, groups, group_weights, 
                                                           comp.data_ptr(), nq, k, nb, g, w, float(min_similarity),
                                                           float(band), _stream_ptr())
     native.check(rc, "tvbf_refine_min_similarity_f64")
+
+
+# ---- float64 re-rank (the reference's order, scores and threshold cut) ----
+
+RERANK_MARGIN = 2e-6  # a float64 score exceeds the fp32 score of the same pair by less than this
+
+
+@dataclass
+class TopK64:
+    """Per-row neighbours in the reference's float64 arithmetic: idx (nq,k) int32 (-1 = unused),
+    score (nq,k) float64, count (nq,) int32, comp (nq,k,3) float64 genre / text / metadata cosines;
+    rows ordered by float64 score descending, equal scores by index ascending.  ``stats`` says how
+    many rows needed a longer candidate list (``resweep``) or a scan of all shows (``scan``)."""
+
+    idx: torch.Tensor
+    score: torch.Tensor
+    count: torch.Tensor
+    comp: torch.Tensor
+    stats: dict
+
+
+def candidate_count(k: int) -> int:
+    """Candidates per show the fp32 sweep collects for a float64 re-rank to k: k + 8 while the
+    lists stay in LDS (k + 8 <= 30), k + 16 beyond (lists in global memory either way)."""
+    k = int(k)
+    return k + 8 if k + 8 <= 30 else max(k, min(k + 16, native.TVBF_MAX_K))
+
+
+def block_norms(sources, n: int, offsets, *, check_finite: bool = True) -> torch.Tensor:
+    """(n, nb) float64 L2 norms of every show's feature blocks (a zero block counts as 1, as in
+    sklearn's normalize).  With ``check_finite`` a NaN or infinite stored value raises ValueError
+    with sklearn's message (the reference's cosine_similarity validates its input; synchronises)."""
+    arr, device = _source_array(sources, n)
+    nb = len(offsets) - 1
+    off = (ctypes.c_int32 * (nb + 1))(*[int(o) for o in offsets])
+    norms = torch.empty((n, nb), dtype=torch.float64, device=device)
+    flag = torch.zeros(1, dtype=torch.int32, device=device) if check_finite else None
+    with torch.cuda.device(device):
+        rc = native.load().tvbf_block_norms_f64(arr, len(sources), n, int(offsets[-1]), off, nb, norms.data_ptr(),
+                                                flag.data_ptr() if flag is not None else None, _stream_ptr())
+    native.check(rc, "tvbf_block_norms_f64")
+    if flag is not None:
+        bits = int(flag.item())
+        if bits & 1:
+            raise ValueError("Input contains NaN.")
+        if bits & 2:
+            raise ValueError("Input contains infinity or a value too large for dtype('float64').")
+    return norms
+
+
+def rescore_topk(sources, n: int, offsets, groups, group_weights, norms: torch.Tensor, cand: TopK, k: int,
+                 min_similarity: float, out: TopK64, *, q_row0: int = 0, row_ids: torch.Tensor | None = None,
+                 margin: float = RERANK_MARGIN, exclude_self: bool = True,
+                 flagged: torch.Tensor | None = None) -> None:
+    """One launch of the float64 re-rank: the candidates ``cand`` (kc per row, from an fp32 sweep)
+    of shows ``row_ids`` (int32 on the device; default: shows q_row0 .. q_row0 + rows of cand)
+    re-scored from the stored ``sources`` and written, best k first, into ``out`` (whose row 0 is
+    show q_row0).  ``flagged`` (int32, 1 + rows, [0] zeroed): receives the shows whose list may miss
+    a true neighbour."""
+    arr, device = _source_array(sources, n)
+    nb = len(offsets) - 1
+    nq, kc = cand.idx.shape
+    off = (ctypes.c_int32 * (nb + 1))(*[int(o) for o in offsets])
+    grp = (ctypes.c_int32 * nb)(*[int(g) for g in groups])
+    w = (ctypes.c_double * 3)(*[float(v) for v in group_weights])
+    for t, name, dt in ((cand.idx, "cand.idx", torch.int32), (cand.score, "cand.score", torch.float32),
+                        (cand.count, "cand.count", torch.int32), (norms, "norms", torch.float64),
+                        (out.idx, "out.idx", torch.int32), (out.score, "out.score", torch.float64),
+                        (out.comp, "out.comp", torch.float64), (out.count, "out.count", torch.int32)):
+        _require_cuda(t, name, dt)
+        if not t.is_contiguous():
+            raise ValueError(f"{name} must be contiguous")
+    if out.idx.shape[1] != k or out.score.shape != out.idx.shape or out.comp.shape != out.idx.shape + (3,):
+        raise ValueError("out must hold (rows, k) idx / score and (rows, k, 3) comp")
+    if norms.shape != (n, nb):
+        raise ValueError("norms must be (n, nb)")
+    if row_ids is not None:
+        _require_cuda(row_ids, "row_ids", torch.int32)
+        if row_ids.numel() != nq or not row_ids.is_contiguous():
+            raise ValueError("row_ids needs one contiguous entry per candidate row")
+    elif out.idx.shape[0] < nq:
+        raise ValueError("out has fewer rows than cand")
+    if flagged is not None:
+        _require_cuda(flagged, "flagged", torch.int32)
+        if flagged.numel() < 1 + nq:
+            raise ValueError("flagged needs 1 + rows entries")
+    with torch.cuda.device(device):
+        rc = native.load().tvbf_rescore_topk_f64(
+            arr, len(sources), n, int(offsets[-1]), off, nb, grp, w, norms.data_ptr(),
+            row_ids.data_ptr() if row_ids is not None else None, nq, int(q_row0), cand.idx.data_ptr(),
+            cand.score.data_ptr(), cand.count.data_ptr(), kc, int(k), float(min_similarity), float(margin),
+            1 if exclude_self else 0, out.idx.data_ptr(), out.score.data_ptr(), out.comp.data_ptr(),
+            out.count.data_ptr(), int(q_row0), flagged.data_ptr() if flagged is not None else None, _stream_ptr())
+    native.check(rc, "tvbf_rescore_topk_f64")
+
+
+def score_rows(sources, n: int, offsets, groups, group_weights, norms: torch.Tensor, row_ids: torch.Tensor,
+               *, exclude_self: bool = True) -> torch.Tensor:
+    """(rows, n) float64 scores of the shows ``row_ids`` (int32 on the device) against all shows,
+    in the reference's arithmetic; -inf at a show's own column when ``exclude_self``."""
+    arr, device = _source_array(sources, n)
+    nb = len(offsets) - 1
+    off = (ctypes.c_int32 * (nb + 1))(*[int(o) for o in offsets])
+    grp = (ctypes.c_int32 * nb)(*[int(g) for g in groups])
+    w = (ctypes.c_double * 3)(*[float(v) for v in group_weights])
+    _require_cuda(row_ids, "row_ids", torch.int32)
+    h = torch.empty((row_ids.numel(), n), dtype=torch.float64, device=device)
+    with torch.cuda.device(device):
+        rc = native.load().tvbf_score_rows_f64(arr, len(sources), n, int(offsets[-1]), off, nb, grp, w,
+                                               norms.data_ptr(), row_ids.data_ptr(), row_ids.numel(),
+                                               1 if exclude_self else 0, h.data_ptr(), n, _stream_ptr())
+    native.check(rc, "tvbf_score_rows_f64")
+    return h
+
+
+SCAN_BYTES = 1 << 30  # float64 score rows held at a time by the last-resort scan
+
+
+def exact_topk(z: torch.Tensor, sources, offsets, groups, group_weights, k: int, min_similarity: float, *,
+               n: int | None = None, q_row0: int = 0, nq: int | None = None, cand: TopK | None = None,
+               z_q: torch.Tensor | None = None, resweep=None, norms: torch.Tensor | None = None,
+               margin: float = RERANK_MARGIN, band: float = THRESHOLD_BAND, check_finite: bool = True) -> TopK64:
+    """The reference's top-k lists (scripts/populate_database.py:170-218) for shows
+    q_row0 .. q_row0 + nq: float64 scores, float64 order, float64 threshold cut.
+
+    ``z`` is the normalised fp32 matrix of ALL n shows (the sweeps' column operand) and ``sources``
+    the stored feature arrays of all n shows on the device.  ``z_q`` (rows q_row0 .. of a query-side
+    matrix) is given when the query side differs from ``z`` -- weights applied on one side only.
+    Three stages, each only for the rows the previous one could not certify: (1) the fp32 sweep's
+    :func:`candidate_count` best (``cand``; computed here when not given) re-ranked in float64;
+    (2) ``resweep(rows, kc)`` -- by default a plain fp32 sweep of just those rows -- for the 100
+    best, self not excluded, re-ranked; (3) their float64 scores against all shows and an exact
+    selection.  Reads the number of uncertified rows back between stages."""
+    n = z.shape[0] if n is None else int(n)
+    nq = n - q_row0 if nq is None else int(nq)
+    dev = z.device
+    if norms is None:
+        norms = block_norms(sources, n, offsets, check_finite=check_finite)
+    out = TopK64(torch.empty((nq, k), dtype=torch.int32, device=dev), torch.empty((nq, k), dtype=torch.float64, device=dev),
+                 torch.empty((nq,), dtype=torch.int32, device=dev), torch.empty((nq, k, 3), dtype=torch.float64, device=dev),
+                 {"candidates": 0, "resweep": 0, "scan": 0})
+    if k > native.TVBF_MAX_K:
+        # longer lists than the sweeps keep: every row goes straight to the scan of all shows
+        rows = torch.arange(q_row0, q_row0 + nq, dtype=torch.int32, device=dev)
+        nf = nq
+    else:
+        if cand is None:
+            kc = candidate_count(k)
+            if z_q is not None:
+                cand = cosine_topk(z, kc, min_similarity - band, z_q=z_q, q_row0=q_row0, nq=nq, n=n)
+            elif q_row0 == 0 and nq == n:
+                cand = catalogue_topk(z, kc, min_similarity - band, n=n)
+            else:
+                cand = cosine_topk(z, kc, min_similarity - band, q_row0=q_row0, nq=nq, n=n)
+        kc = cand.idx.shape[1]
+        out.stats["candidates"] = kc
+        flagged = torch.zeros(1 + nq, dtype=torch.int32, device=dev)
+        rescore_topk(sources, n, offsets, groups, group_weights, norms, cand, k, min_similarity, out, q_row0=q_row0,
+                     margin=margin, flagged=flagged)
+        nf = int(flagged[0].item())
+        if nf == 0:
+            return out
+        rows = flagged[1:1 + nf].sort().values.contiguous()
+        kc2 = native.TVBF_MAX_K
+        if kc2 > kc:  # stage 2: a longer list for just these rows
+            out.stats["resweep"] = nf
+            if resweep is None:
+                def resweep(ids, kk):
+                    zq = z.index_select(0, ids.long()) if z_q is None else z_q.index_select(0, ids.long() - q_row0)
+                    return cosine_topk(z, kk, min_similarity - band, z_q=zq, n=n, exclude_self=False)
+            cand2 = resweep(rows, kc2)
+            flagged2 = torch.zeros(1 + nf, dtype=torch.int32, device=dev)
+            rescore_topk(sources, n, offsets, groups, group_weights, norms, cand2, k, min_similarity, out,
+                         q_row0=q_row0, row_ids=rows, margin=margin, flagged=flagged2)
+            nf = int(flagged2[0].item())
+            if nf == 0:
+                return out
+            rows = flagged2[1:1 + nf].sort().values.contiguous()
+    out.stats["scan"] = nf
+    batch = max(1, min(nf, SCAN_BYTES // (8 * n), 65535))
+    for b0 in range(0, nf, batch):  # stage 3: every score of the row in float64, exact selection
+        ids = rows[b0:b0 + batch].contiguous()
+        h = score_rows(sources, n, offsets, groups, group_weights, norms, ids)
+        idx, _, count = dense_rows_topk(h, k, min_similarity, exclude_self=False)
+        cand3 = TopK(idx, torch.zeros(idx.shape, dtype=torch.float32, device=dev), count)
+        rescore_topk(sources, n, offsets, groups, group_weights, norms, cand3, k, min_similarity, out, q_row0=q_row0,
+                     row_ids=ids, margin=float("-inf"))
+        del h
+    return out
 
 
 def gram(z_all: torch.Tensor, *, col0: int = 0, width: int | None = None, q_row0: int = 0,

@@ -31,7 +31,7 @@ class TopKResult:
     """Neighbours of every show, in row order of the feature matrices.
 
     idx    (n, k) int32 column index of each neighbour, -1 in unused slots
-    score  (n, k) float32 hybrid similarity, descending
+    score  (n, k) float64 hybrid similarity, descending
     count  (n,)   int32 neighbours kept (score >= min_similarity, at most k)
     comp   (n, k, 3) float64 genre / text / metadata cosine of each kept pair
     """
@@ -169,28 +169,26 @@ class SimilarityComputer:
         return {"mean": float(out[0]), "std": float(out[1]), "min": float(out[2]),
                 "max": float(out[3]), "median": float(out[4])}
 
-    def get_feature_statistics(self, features: dict) -> dict:
-        """The four statistics blocks that scripts/compute_similarities.py:119-131 logs (genre,
-        text, metadata, hybrid), each what :meth:`get_similarity_statistics` returns for that
-        matrix, computed from the features without forming any n x n matrix."""
-        import torch
-
+    def _device_sources(self, features: dict, variant: str):
+        """The five stored feature arrays on the device, their column layout, and the number of shows."""
         from .. import engine
 
         dev = _torch_device(self.device)
         sources, layout = feat.block_sources(features, self.genre_weight, self.text_weight,
-                                             self.metadata_weight, "computer")
+                                             self.metadata_weight, variant)
         n = int(sources[0][1].shape[0]) - (1 if sources[0][0] == "csr" else 0)
+        return engine.upload_sources(sources, dev), layout, n
+
+    def get_feature_statistics(self, features: dict) -> dict:
+        """The four statistics blocks that scripts/compute_similarities.py:119-131 logs (genre,
+        text, metadata, hybrid), each what :meth:`get_similarity_statistics` returns for that
+        matrix, computed from the features without forming any n x n matrix."""
+        from .. import engine
+
+        dev_sources, layout, n = self._device_sources(features, "computer")
         if n < 2:
             raise ValueError("zero-size array to reduction operation minimum which has no identity")
-        dev_sources = []
-        for src in sources:
-            if src[0] == "dense":
-                dev_sources.append(engine.DenseSource(torch.from_numpy(src[1]).to(dev), src[2]))
-            else:
-                _, indptr, indices, data, width, z_col = src
-                dev_sources.append(engine.CsrSource(torch.from_numpy(indptr).to(dev), torch.from_numpy(indices).to(dev),
-                                                    torch.from_numpy(data).to(dev), width, z_col))
+        engine.block_norms(dev_sources, n, layout.offsets)  # sklearn's input validation: NaN / infinity raise
         out = {}
         hybrid_scales = layout.scales()
         for name, scales in (("genre_similarity", [1.0, 0.0, 0.0]), ("text_similarity", [0.0, 1.0, 0.0]),
@@ -204,6 +202,15 @@ class SimilarityComputer:
 
     # ---- scalable entry point: no n x n matrix ----
 
+    def group_weights(self, variant: str) -> list:
+        """The three weights of the reference's hybrid expression: raw for the production loop
+        (scripts/populate_database.py:190-192), divided by their sum for this class
+        (ml/similarity_computer.py:112-115)."""
+        if variant == "populate":
+            return [self.genre_weight, self.text_weight, self.metadata_weight]
+        total = self.genre_weight + self.text_weight + self.metadata_weight
+        return [self.genre_weight / total, self.text_weight / total, self.metadata_weight / total]
+
     def topk(self, features: dict, k: int = 20, min_similarity: float = 0.1,
              variant: str = "computer") -> TopKResult:
         """Top-k hybrid neighbours of every show straight from the feature blocks.
@@ -212,37 +219,28 @@ class SimilarityComputer:
         "computer" (this class: metadata = cosine of the concatenation, weights
         divided by their sum) or "populate" (scripts/populate_database.py:184-192:
         metadata = mean of three cosines, raw weights).
-        """
-        import torch
 
+        The fp32 MFMA sweep collects a few more than k candidates per show a hair below the
+        threshold; their scores are then recomputed in float64 from the stored arrays, so the
+        order, the scores and the ``score < min_similarity`` cut are the reference's own float64
+        decisions (scripts/populate_database.py:190-218); equal float64 scores go by index.
+        """
         from .. import engine
 
-        dev = _torch_device(self.device)
         # the stored arrays go to the device as they are (CSR text stays CSR); Z is built there
-        sources, layout = feat.block_sources(features, self.genre_weight, self.text_weight,
-                                             self.metadata_weight, variant)
-        dev_sources = []
-        for src in sources:
-            if src[0] == "dense":
-                dev_sources.append(engine.DenseSource(torch.from_numpy(src[1]).to(dev), src[2]))
-            else:
-                _, indptr, indices, data, width, z_col = src
-                dev_sources.append(engine.CsrSource(torch.from_numpy(indptr).to(dev), torch.from_numpy(indices).to(dev),
-                                                    torch.from_numpy(data).to(dev), width, z_col))
-        n = int(sources[0][1].shape[0]) - (1 if sources[0][0] == "csr" else 0)
-        scales = layout.scales()
-        z = engine.assemble_normalize(dev_sources, n, layout.offsets, scales)
-        # the sweep compares fp32 scores: it runs a hair below the threshold, and the pairs in that
-        # band are decided in float64 from their per-block cosines exactly as the reference does
-        top = engine.catalogue_topk(z, k, min_similarity - engine.THRESHOLD_BAND)
-        cscales = layout.component_scales()
-        zc = z if cscales == scales else engine.assemble_normalize(dev_sources, n, layout.offsets, cscales)
-        comp = engine.component_scores(zc, layout.offsets, cscales, top.idx)
-        if variant == "populate":  # raw weights (scripts/populate_database.py:190-192)
-            group_weights = [self.genre_weight, self.text_weight, self.metadata_weight]
-        else:  # divided by their sum (ml/similarity_computer.py:112-115)
-            total = self.genre_weight + self.text_weight + self.metadata_weight
-            group_weights = [self.genre_weight / total, self.text_weight / total, self.metadata_weight / total]
-        engine.refine_min_similarity(top, comp, layout.groups, group_weights, min_similarity)
+        dev_sources, layout, n = self._device_sources(features, variant)
+        norms = engine.block_norms(dev_sources, n, layout.offsets)  # raises on NaN / infinity, as sklearn does
+        if min(layout.weights) >= 0:
+            # Z = [sqrt(w_b) * unit block]: Z Z^T is the hybrid matrix, every pair computed once
+            z = engine.assemble_normalize(dev_sources, n, layout.offsets, layout.scales())
+            z_q = None
+        else:
+            # a negative weight has no square root: unit blocks on the column side, the weights on the
+            # query side only (a plain sweep; the reference accepts any weights, ml/similarity_computer.py:112-124)
+            z = engine.assemble_normalize(dev_sources, n, layout.offsets, [1.0] * layout.nb)
+            z_q = engine.assemble_normalize(dev_sources, n, layout.offsets, [float(w) for w in layout.weights])
+        top = engine.exact_topk(z, dev_sources, layout.offsets, layout.groups, self.group_weights(variant),
+                                k, min_similarity, n=n, norms=norms, z_q=z_q)
+        self.last_topk_stats = dict(top.stats)
         return TopKResult(top.idx.cpu().numpy(), top.score.cpu().numpy(), top.count.cpu().numpy(),
-                          feat.fold_components(comp.cpu().numpy(), layout))
+                          top.comp.cpu().numpy())

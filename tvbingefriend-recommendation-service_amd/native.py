@@ -16,7 +16,7 @@ CSRC = Path(__file__).resolve().parent / "csrc"
 INCLUDE = Path(__file__).resolve().parent.parent / "include"
 # TVBF_LIB selects another build of the same ABI (timing-only diagnostic variants under build/)
 LIB_PATH = Path(os.environ["TVBF_LIB"]) if os.environ.get("TVBF_LIB") else CSRC / "libtvbf.so"
-SOURCES = [CSRC / "tvbf_kernels.hip", CSRC / "tvbf_stats.hip", CSRC / "tvbf_assemble.hip"]
+SOURCES = [CSRC / "tvbf_kernels.hip", CSRC / "tvbf_stats.hip", CSRC / "tvbf_assemble.hip", CSRC / "tvbf_rescore.hip"]
 
 # Every symbol include/tvbf.h declares.
 SYMBOLS = (
@@ -54,6 +54,9 @@ SYMBOLS = (
     "tvbf_gram_stats_inspect",
     "tvbf_component_scores_f32",
     "tvbf_refine_min_similarity_f64",
+    "tvbf_block_norms_f64",
+    "tvbf_rescore_topk_f64",
+    "tvbf_score_rows_f64",
     "tvbf_weighted_sum3_f64",
     "tvbf_stats_workspace_bytes",
     "tvbf_upper_tri_stats_f64",
@@ -217,6 +220,16 @@ def load() -> ctypes.CDLL:
     lib.tvbf_refine_min_similarity_f64.restype = c.c_int
     lib.tvbf_refine_min_similarity_f64.argtypes = [vp, vp, vp, vp, i64, c.c_int, c.c_int, c.POINTER(i32),
                                                    c.POINTER(c.c_double), c.c_double, c.c_double, vp]
+    f64 = c.c_double
+    lib.tvbf_block_norms_f64.restype = c.c_int
+    lib.tvbf_block_norms_f64.argtypes = [c.POINTER(Source), c.c_int, i64, i64, c.POINTER(i32), c.c_int, vp, vp, vp]
+    lib.tvbf_rescore_topk_f64.restype = c.c_int
+    lib.tvbf_rescore_topk_f64.argtypes = [c.POINTER(Source), c.c_int, i64, i64, c.POINTER(i32), c.c_int,
+                                          c.POINTER(i32), c.POINTER(f64), vp, vp, i64, i64, vp, vp, vp, c.c_int,
+                                          c.c_int, f64, f64, c.c_int, vp, vp, vp, vp, i64, vp, vp]
+    lib.tvbf_score_rows_f64.restype = c.c_int
+    lib.tvbf_score_rows_f64.argtypes = [c.POINTER(Source), c.c_int, i64, i64, c.POINTER(i32), c.c_int,
+                                        c.POINTER(i32), c.POINTER(f64), vp, vp, i64, c.c_int, vp, i64, vp]
     lib.tvbf_topk_max_slots.restype = c.c_int
     lib.tvbf_topk_max_slots.argtypes = [c.c_int]
     lib.tvbf_topk_workspace_bytes_for_slots.restype = sz

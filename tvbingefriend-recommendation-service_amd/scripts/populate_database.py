@@ -69,7 +69,7 @@ def neighbour_records(result: TopKResult, show_ids, start: int, stop: int, use_e
             ids = np.ascontiguousarray(ids, dtype=np.int64)
             k = int(np.asarray(result.idx).shape[1])
             return ext.records(ids, np.ascontiguousarray(result.idx, dtype=np.int32),
-                               np.ascontiguousarray(result.score, dtype=np.float32),
+                               np.ascontiguousarray(result.score, dtype=np.float64),
                                np.ascontiguousarray(result.comp, dtype=np.float64),
                                np.ascontiguousarray(result.count, dtype=np.int32), k, int(start), int(stop))
     idx = np.asarray(result.idx[start:stop])
@@ -116,7 +116,7 @@ def neighbour_table(result: TopKResult, show_ids) -> dict:
 
     comp = kept(result.comp, 3)
     return {
-        "show_id": np.repeat(ids, np.minimum(count, k)),
+        "show_id": np.repeat(ids[: len(count)], np.minimum(count, k)),
         "similar_show_id": ids[kept(result.idx)],
         "similarity_score": kept(result.score).astype(np.float64),
         "genre_score": comp[:, 0].astype(np.float64),
@@ -137,7 +137,7 @@ def iter_table_rows(table: dict, batch_size: int = 1000):
 
 def write_table_csv(table: dict, path, header: bool = True) -> int:
     """The table as a CSV file for a bulk loader (``LOAD DATA INFILE`` / ``COPY``); returns the
-    number of rows.  Scores are written with 9 significant digits (exact for fp32)."""
+    number of rows.  Scores are written with 17 significant digits (exact for float64)."""
     n = len(table["show_id"])
     with open(path, "w", encoding="utf-8", newline="") as f:
         if header:
@@ -146,7 +146,7 @@ def write_table_csv(table: dict, path, header: bool = True) -> int:
         for start in range(0, n, block):
             stop = min(n, start + block)
             cols = [table[c][start:stop] for c in TABLE_COLUMNS]
-            lines = ["%d,%d,%.9g,%.9g,%.9g,%.9g" % row for row in zip(*[c.tolist() for c in cols])]
+            lines = ["%d,%d,%.17g,%.17g,%.17g,%.17g" % row for row in zip(*[c.tolist() for c in cols])]
             f.write("\n".join(lines) + "\n")
     return n
 

@@ -51,6 +51,8 @@ class ContentBasedRecommendationService:
         self._metadata_similarity = None
         self._hybrid_similarity = None
         self._feature_z = None             # torch fp32 (n, ld): per-block unit rows, kept in HBM
+        self._feature_sources = None       # the stored feature arrays on the device
+        self._feature_norms = None         # (n, nb) float64 block norms
         self._feature_layout = None
         self._show_id_to_index: dict | None = None
         self._index_to_show_id: dict | None = None
@@ -135,26 +137,19 @@ class ContentBasedRecommendationService:
 
     def _load_feature_matrix(self):
         """The five feature files of scripts/compute_features.py:115-129 -> block-normalised Z
-        on the GPU (unit scale per block, so any weighting can be applied to a query vector)."""
+        on the GPU (unit scale per block, so any weighting can be applied to a query vector); the
+        stored arrays and their float64 block norms stay on the device for the float64 re-rank."""
         if self._feature_z is not None:
             return
-        import torch
-
         from .. import engine, features as feat
         from ..scripts.compute_similarities import load_features
 
         dev = self._device()
         sources, layout = feat.block_sources(load_features(self._get_data_dir()), 1.0, 1.0, 1.0, "computer")
-        dev_sources = []
-        for src in sources:
-            if src[0] == "dense":
-                dev_sources.append(engine.DenseSource(torch.from_numpy(src[1]).to(dev), src[2]))
-            else:
-                _, indptr, indices, data, width, z_col = src
-                dev_sources.append(engine.CsrSource(torch.from_numpy(indptr).to(dev), torch.from_numpy(indices).to(dev),
-                                                    torch.from_numpy(data).to(dev), width, z_col))
         n = int(sources[0][1].shape[0]) - (1 if sources[0][0] == "csr" else 0)
-        self._feature_z = engine.assemble_normalize(dev_sources, n, layout.offsets, [1.0] * layout.nb)
+        self._feature_sources = engine.upload_sources(sources, dev)
+        self._feature_norms = engine.block_norms(self._feature_sources, n, layout.offsets)
+        self._feature_z = engine.assemble_normalize(self._feature_sources, n, layout.offsets, [1.0] * layout.nb)
         self._feature_layout = layout
         logger.info(f"✓ Feature matrix on device: {tuple(self._feature_z.shape)}")
 
@@ -164,7 +159,8 @@ class ContentBasedRecommendationService:
         """Same records as :meth:`get_recommendations_from_matrix`, computed from the feature
         files with one pass over the catalogue instead of stored n x n matrices; the weights
         default to the service's and may differ per call (normalised by their sum as in the
-        reference, services/content_based_service.py:133-138)."""
+        reference, services/content_based_service.py:133-138; negative weights are fine: they
+        scale the query vector only).  Scores, order and the threshold cut are float64."""
         from .. import engine
 
         self._load_feature_matrix()
@@ -177,18 +173,20 @@ class ContentBasedRecommendationService:
         mw = self.metadata_weight if metadata_weight is None else metadata_weight
         total = gw + tw + mw
         weights = [gw / total, tw / total, mw / total]
-        if min(weights) < 0:
-            raise ValueError("similarity weights must be >= 0")
         z, layout = self._feature_z, self._feature_layout
         row = self._show_id_to_index[show_id]
         q = z[row:row + 1].clone()
         for b in range(layout.nb):
             q[:, layout.offsets[b]:layout.offsets[b + 1]] *= weights[b]
-        top = engine.query_topk(q, z, max(n, 1), min_similarity - engine.THRESHOLD_BAND, self_index=[row])
-        comp = engine.component_scores(z, layout.offsets, [1.0] * layout.nb, top.idx, q_row0=row)
-        # pairs within a hair of the threshold are decided in float64, as the reference decides them
-        engine.refine_min_similarity(top, comp, layout.groups, weights, min_similarity)
-        comp = comp.cpu().numpy()[0]
+        k = max(n, 1)
+        floor = min_similarity - engine.THRESHOLD_BAND
+        cand = None
+        if k <= native.TVBF_MAX_K:
+            cand = engine.query_topk(q, z, engine.candidate_count(k), floor, self_index=[row])
+        top = engine.exact_topk(z, self._feature_sources, layout.offsets, layout.groups, weights, k, min_similarity,
+                                q_row0=row, nq=1, cand=cand, norms=self._feature_norms,
+                                resweep=lambda ids, kk: engine.query_topk(q, z, kk, floor))
+        comp = top.comp.cpu().numpy()[0]
         return self._records(top.idx.cpu().numpy()[0], top.score.cpu().numpy()[0], int(top.count.cpu().numpy()[0]),
                              [comp[:, 0], comp[:, 1], comp[:, 2]], "show_id")
 

@@ -378,6 +378,8 @@ def sharded_topk_symmetric(x_shard: torch.Tensor, offsets, scales, shard: Shard,
         from . import engine
 
         mbytes = engine.own_matrix_bytes(shard.rows, z_shard.shape[1])
+        if mbytes > engine.MEMORY_HEADROOM * engine.available_bytes(z_shard.device):
+            mbytes = 0  # not enough memory for the stored own block: the fused own-block sweeps give the same lists
         own_matrix = torch.empty((mbytes + 7) // 8, dtype=torch.int64, device=z_shard.device) if mbytes else None
         job = job_fn(z_shard, shard, k, min_similarity, own_matrix=own_matrix)
     else:
