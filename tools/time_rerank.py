@@ -69,6 +69,10 @@ def main():
         stats.update(engine.exact_topk(z, src, offsets, groups, weights, k, ms, norms=norms).stats)
 
     t_exact = timed(torch, whole, reps=3)
+    for rk in (48, 64, 100):
+        st2 = {}
+        t = timed(torch, lambda: st2.update(engine.exact_topk(z, src, offsets, groups, weights, k, ms, norms=norms, resweep_k=rk).stats), reps=3)
+        print(f"  second stage with {rk} candidates: {t:.2f} ms, stages {st2}")
     print(f"n={n} d={d} k={k} {kind}: fp32 call K={k} {t_k:.2f} ms, K'={kc} {t_kc:.2f} ms, K5 {t_k5:.2f} ms, "
           f"norms {t_norms:.3f} ms, rescore launch {t_rescore:.2f} ms, exact_topk (all stages) {t_exact:.2f} ms, stages {stats}")
 

@@ -434,6 +434,12 @@ def candidate_count(k: int) -> int:
     return k + 8 if k + 8 <= 30 else max(k, min(k + 16, native.TVBF_MAX_K))
 
 
+def resweep_candidate_count(k: int) -> int:
+    """Candidates per show of the second stage (rows whose first list ended inside a group of tied
+    scores): 2 k + 16, at least 48, at most the sweeps' limit."""
+    return max(int(k), min(native.TVBF_MAX_K, max(48, 2 * int(k) + 16)))
+
+
 def block_norms(sources, n: int, offsets, *, check_finite: bool = True) -> torch.Tensor:
     """(n, nb) float64 L2 norms of every show's feature blocks (a zero block counts as 1, as in
     sklearn's normalize).  With ``check_finite`` a NaN or infinite stored value raises ValueError
@@ -526,8 +532,8 @@ SCAN_BYTES = 1 << 30  # float64 score rows held at a time by the last-resort sca
 
 def exact_topk(z: torch.Tensor, sources, offsets, groups, group_weights, k: int, min_similarity: float, *,
                n: int | None = None, q_row0: int = 0, nq: int | None = None, cand: TopK | None = None,
-               z_q: torch.Tensor | None = None, resweep=None, norms: torch.Tensor | None = None,
-               margin: float = RERANK_MARGIN, band: float = THRESHOLD_BAND, check_finite: bool = True) -> TopK64:
+               z_q: torch.Tensor | None = None, resweep=None, resweep_k: int | None = None,
+               norms: torch.Tensor | None = None, margin: float = RERANK_MARGIN, band: float = THRESHOLD_BAND, check_finite: bool = True) -> TopK64:
     """The reference's top-k lists (scripts/populate_database.py:170-218) for shows
     q_row0 .. q_row0 + nq: float64 scores, float64 order, float64 threshold cut.
 
@@ -536,8 +542,8 @@ def exact_topk(z: torch.Tensor, sources, offsets, groups, group_weights, k: int,
     matrix) is given when the query side differs from ``z`` -- weights applied on one side only.
     Three stages, each only for the rows the previous one could not certify: (1) the fp32 sweep's
     :func:`candidate_count` best (``cand``; computed here when not given) re-ranked in float64;
-    (2) ``resweep(rows, kc)`` -- by default a plain fp32 sweep of just those rows -- for the 100
-    best, self not excluded, re-ranked; (3) their float64 scores against all shows and an exact
+    (2) ``resweep(rows, kc)`` -- by default a plain fp32 sweep of just those rows -- for a longer
+    list (:func:`resweep_candidate_count`), self not excluded, re-ranked; (3) their float64 scores against all shows and an exact
     selection.  Reads the number of uncertified rows back between stages."""
     n = z.shape[0] if n is None else int(n)
     nq = n - q_row0 if nq is None else int(nq)
@@ -569,7 +575,7 @@ def exact_topk(z: torch.Tensor, sources, offsets, groups, group_weights, k: int,
         if nf == 0:
             return out
         rows = flagged[1:1 + nf].sort().values.contiguous()
-        kc2 = native.TVBF_MAX_K
+        kc2 = resweep_candidate_count(k) if resweep_k is None else int(resweep_k)
         if kc2 > kc:  # stage 2: a longer list for just these rows
             out.stats["resweep"] = nf
             if resweep is None:
