@@ -3,10 +3,17 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over the whole synthetic catalogue:
-normalise+weight the feature blocks (K1) -> [all-gather of the normalised
-shards when N > 1] -> fused all-pairs similarity + per-row top-K (K2-K4) ->
-per-block scores of the kept pairs (K5).  Inputs are resident in HBM when the
+One "step" = one pass of the hot path over the whole synthetic catalogue, as the
+drop-in runs it (--path exact, the default): build the normalised, weighted
+matrix from the stored features (K1) -> [all-gather of the normalised shards
+when N > 1] -> fused all-pairs similarity + per-row top-(K + slack) in fp32
+(K2-K4) -> float64 re-rank of the candidates from the stored features (order,
+scores, threshold cut and per-block scores of the reference's float64
+arithmetic; rows that cannot be certified get a longer list or a scan).
+--path fp32 stops at the fp32 lists (+ K5), the step of the earlier rounds; a
+few such steps are timed after the main region and reported beside it.
+Inputs (the stored features of ALL shows, as every rank of the reference's
+pipeline would load them from the feature files) are resident in HBM when the
 timed region starts.  Metric: ordered show-pairs per second = n^2 * steps /
 time, over the whole job.  The total catalogue is fixed as the GPU count grows
 (strong scaling): rank r owns rows [r*n/N, (r+1)*n/N).
@@ -30,8 +37,11 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # 256 CU x 256 flop/clk x 2.4 GHz, v_mfma_f32_32x
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--path", choices=["exact", "fp32"], default="exact",
+                    help="exact: the drop-in's step (fp32 sweep for K + slack candidates, float64 re-rank); "
+                         "fp32: the fp32 lists and K5 only")
     ap.add_argument("--n", "--shows", dest="n", type=int, default=100_000, help="shows")
     ap.add_argument("--d", "--dims", dest="d", type=int, default=1024, help="feature columns (genre 32 | text d-64 | metadata 32)")
     ap.add_argument("--k", "--neighbours", dest="k", type=int, default=20)
@@ -145,49 +155,45 @@ def cpu_baseline(x_host, offsets, weights, k, min_similarity, budget_s):
     }
 
 
-def end_to_end(x_host, offsets, scales, k, min_similarity, dev):
-    """One pass from host feature matrix to host neighbour table, timed with the wall clock: what a
-    caller of the drop-in pays on top of the device step (reported beside `value`, never inside it).
-    Upload of X from pageable memory, K1 + sweeps + K5, download of the lists and per-block scores,
-    the columnar table, and the reference's dict-of-records form of the same pairs."""
+def end_to_end(x_host, offsets, weights, k, min_similarity, dev):
+    """One pass of the drop-in from host feature arrays to host neighbour table, timed with the wall
+    clock: what a caller pays on top of the device step (reported beside `value`, never inside it).
+    The packed matrix is first split into the reference's five arrays in their stored form (int64
+    genres, CSR float64 text, float64 / bool one-hots; untimed); then
+    scripts.populate_database.compute_top_neighbours -- upload, assembly, norms, sweep, float64
+    re-rank, download -- the columnar table, and the reference's dict-of-records form."""
     import numpy as np
+    import scipy.sparse as sp
     import torch
 
-    from tvbingefriend_recommendation_service_amd import engine
-    from tvbingefriend_recommendation_service_amd.ml.similarity_computer import TopKResult
-    from tvbingefriend_recommendation_service_amd.scripts.populate_database import neighbour_records, neighbour_table
+    from tvbingefriend_recommendation_service_amd.scripts.populate_database import (
+        compute_top_neighbours, neighbour_records, neighbour_table)
 
     n = x_host.shape[0]
+    g, tx, m = (x_host[:, offsets[b] : offsets[b + 1]] for b in range(3))
+    feats = {"genre_features": g.astype(np.int64), "text_features": sp.csr_matrix(tx.astype(np.float64)),
+             "platform_features": m[:, :21].astype(np.float64), "type_features": m[:, 21:26].astype(bool),
+             "language_features": m[:, 26:].astype(np.float64)}
     show_ids = list(range(1, n + 1))
     torch.cuda.synchronize()
     t = [time.perf_counter()]
-
-    def mark():
-        torch.cuda.synchronize()
-        t.append(time.perf_counter())
-
-    x_dev = torch.from_numpy(x_host).to(dev)
-    mark()
-    z = engine.normalize_blocks(x_dev, offsets, scales)
-    top = engine.catalogue_topk(z, k, min_similarity)
-    comp = engine.component_scores(z, offsets, scales, top.idx)
-    mark()
-    result = TopKResult(top.idx.cpu().numpy(), top.score.cpu().numpy(), top.count.cpu().numpy(),
-                        comp.cpu().numpy().astype(np.float64))
-    mark()
+    result = compute_top_neighbours(feats, weights[0], weights[1], weights[2], k, min_similarity, device=dev)
+    torch.cuda.synchronize()
+    t.append(time.perf_counter())
     table = neighbour_table(result, show_ids)
     t.append(time.perf_counter())
     records = neighbour_records(result, show_ids, 0, n)
     t.append(time.perf_counter())
     d = [b - a for a, b in zip(t, t[1:])]
     return {
-        "host_features_to_host_table_s": sum(d[:4]),
-        "upload_s": d[0], "device_s": d[1], "download_s": d[2], "columnar_table_s": d[3],
+        "host_features_to_host_table_s": d[0] + d[1],
+        "compute_top_neighbours_s": d[0], "columnar_table_s": d[1],
         "pairs_kept": int(len(table["show_id"])),
-        "record_dicts_s": d[4], "shows_with_records": len(records),
-        "note": "single pass, cold allocations included; record_dicts_s = the reference's dict[int, list[dict]] form "
-                "built from the same arrays (csrc/_tvbf_records.so when it is built, else a Python loop), not part of "
-                "host_features_to_host_table_s",
+        "record_dicts_s": d[2], "shows_with_records": len(records),
+        "note": "single pass of the drop-in (upload from pageable memory, assembly from CSR / dense sources, fp32 sweep, "
+                "float64 re-rank, download), cold allocations included; record_dicts_s = the reference's "
+                "dict[int, list[dict]] form built from the same arrays (csrc/_tvbf_records.so when it is built, else a "
+                "Python loop), not part of host_features_to_host_table_s",
     }
 
 
@@ -266,18 +272,45 @@ def main():
     ld = engine.padded_ld(args.d)
 
     # persistent buffers: the large ones are allocated once, outside the timed region
+    exact = args.path == "exact"
+    kc = engine.candidate_count(args.k) if exact else args.k       # candidates per show the sweep collects
+    sweep_min = min_sim - engine.THRESHOLD_BAND if exact else min_sim
     z_shard = torch.empty((shard.per_rank, ld), dtype=torch.float32, device=dev)
     z_all = z_shard if world == 1 else torch.empty((shard.padded_total, ld), dtype=torch.float32, device=dev)
     nq = shard.rows
-    out = engine.TopK(torch.empty((nq, args.k), dtype=torch.int32, device=dev),
-                      torch.empty((nq, args.k), dtype=torch.float32, device=dev),
-                      torch.empty((nq,), dtype=torch.int32, device=dev))
+    groups = [0, 1, 2][: len(weights)]
+    gw = (list(weights) + [0.0, 0.0])[:3]
+    if exact:
+        # the stored features of ALL shows on every rank (what every rank of the reference's pipeline
+        # loads from the feature files): gathered once, before the timed region
+        if world == 1:
+            x_all = x
+        elif args.backend == "nccl":
+            x_all = torch.empty((shard.padded_total, args.d), dtype=torch.float32, device=dev)
+            dist.all_gather_into_tensor(x_all, x)
+        else:
+            parts = [torch.empty((shard.per_rank, args.d), dtype=torch.float32) for _ in range(world)]
+            dist.all_gather(parts, x.cpu())
+            x_all = torch.cat(parts, dim=0).to(dev)
+        src_all = [engine.DenseSource(x_all[: args.n], 0)]
+        src_shard = [engine.DenseSource(x, 0)]
+        out64 = None
+
+    def new_out(kk):
+        return engine.TopK(torch.empty((nq, kk), dtype=torch.int32, device=dev),
+                           torch.empty((nq, kk), dtype=torch.float32, device=dev),
+                           torch.empty((nq,), dtype=torch.int32, device=dev))
+
+    out = new_out(kc)
     slots = 16 if world == 1 else 32
-    ws_bytes = int(native.load().tvbf_topk_workspace_bytes_for_slots(max(nq, 1), args.k, slots))
+    ws_bytes = int(native.load().tvbf_topk_workspace_bytes_for_slots(max(nq, 1), kc, slots))
     workspace = torch.empty((ws_bytes + 15) // 16 * 2, dtype=torch.int64, device=dev)
-    sym_bytes = engine.symmetric_workspace_bytes(args.n, ld, args.k) if args.sweep != "plain" else 0
-    if world > 1 and not sharding.symmetric_route_fits(world, args.k, ld):
+    sym_bytes = engine.symmetric_workspace_bytes(args.n, ld, kc) if args.sweep != "plain" else 0
+    if world > 1 and not sharding.symmetric_route_fits(world, kc, ld):
         sym_bytes = 0
+    if world == 1 and sym_bytes and args.sweep == "auto" and engine.choose_catalogue_route(
+            sym_bytes, ws_bytes, engine.available_bytes(dev)) != "symmetric":
+        sym_bytes = 0  # not enough free memory for its score matrices and column buffers: same lists from the plain sweep
     if args.sweep == "symmetric" and not sym_bytes:
         raise SystemExit("--sweep symmetric: row length a multiple of 64, more than 1920 shows, and for several "
                          "GPUs a K small enough that one merge takes all lists")
@@ -298,9 +331,9 @@ def main():
         failed = 0.0
         if symmetric:  # lists of the own, half and (gated) plain sweeps; column buffers of all shows
             try:
-                sym_ws_bytes = int(native.load().tvbf_topk_workspace_bytes_for_slots(max(nq, 1), args.k, 96))
+                sym_ws_bytes = int(native.load().tvbf_topk_workspace_bytes_for_slots(max(nq, 1), kc, 96))
                 sym_workspace = torch.empty((sym_ws_bytes + 15) // 16 * 2, dtype=torch.int64, device=dev)
-                side = engine.ColumnSide(shard.padded_total, dev, cap=1024)
+                side = engine.ColumnSide(shard.padded_total, dev, cap=1024 if kc <= 64 else 2048)
                 torch.cuda.synchronize()
             except Exception as e:  # noqa: BLE001
                 failed = 1.0
@@ -313,14 +346,16 @@ def main():
         elif symmetric:
             slots, workspace = 96, sym_workspace
     # a rank's own block (its rows against their own columns) goes through the stored-matrix route
-    # when it is small enough for it: the buffer is allocated once
+    # when it is small enough for it and the memory is there: the buffer is allocated once
     own_matrix = None
     if world > 1 and args.sweep != "plain":
         mbytes = engine.own_matrix_bytes(nq, ld)
-        if mbytes:
+        if mbytes and mbytes <= engine.MEMORY_HEADROOM * engine.available_bytes(dev):
             own_matrix = torch.empty((mbytes + 7) // 8, dtype=torch.int64, device=dev)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     kernel_ms = []
+    phase_marks = []  # per timed step: [(name, event), ...] on the compute stream
+    rerank_stats = {}
     tiles_step = [0]  # 128 x 128 score tiles the sweeps of one step compute on this rank
     own, after, before = sharding.column_pieces(shard)
 
@@ -343,48 +378,85 @@ def main():
             return dist.all_gather_into_tensor(z_all, z_shard, async_op=True)
         return HostGather()
 
-    def step(timed):
-        engine.normalize_blocks(x, offsets, scales, out=z_shard)
+    def step(timed, path_exact=exact):
+        marks = []
+
+        def mark(name):
+            # phase boundary on the compute stream; an event after work.wait() completes when the
+            # gathered shards are there, so "gather_wait" is the part of the all-gather not hidden
+            if timed:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                marks.append((name, e))
+
+        kk = kc if path_exact else args.k
+        ms_sweep = sweep_min if path_exact else min_sim
+        res = out if kk == kc else out_k
+        mark("start")
+        if path_exact:  # the drop-in's K1: assembled from the stored arrays (here one dense fp32 source)
+            engine.assemble_normalize(src_shard, shard.per_rank, offsets, scales, out=z_shard)
+        else:
+            engine.normalize_blocks(x, offsets, scales, out=z_shard)
+        mark("k1")
         work = start_gather()
         if symmetric and world == 1:
             if timed:
                 ev[0].record()
-            engine.cosine_topk_symmetric(z_shard, args.k, min_sim, n=nq, workspace=workspace, out=out)
-            tiles_step[0] = engine.symmetric_tiles(nq, ld, args.k, dev)
+            engine.cosine_topk_symmetric(z_shard, kk, ms_sweep, n=nq, workspace=workspace, out=res)
+            tiles_step[0] = engine.symmetric_tiles(nq, ld, kk, dev)
         elif symmetric:
-            job = sharding.SymmetricShardJob(z_shard, shard, args.k, min_sim, slots=slots, workspace=workspace,
+            job = sharding.SymmetricShardJob(z_shard, shard, kk, ms_sweep, slots=slots, workspace=workspace,
                                              colside=side, own_matrix=own_matrix)
             if timed:
                 ev[0].record()
             job.phase_own()  # overlaps the all-gather of Z
+            mark("own")
             bounds_all = sharding.gather_words(job.own_bounds(), world)
+            mark("bounds_gather")
             work.wait()
+            mark("gather_wait")
             job.phase_half(z_all, bounds_all)
-            send = job.lists_for_peers(bounds_all)
-            flag = sharding.reduce_flag(job.flag)
-            recv = sharding.exchange_lists(send)
-            job.finish(z_all, recv, flag, out)
+            mark("half")
+            packed = sharding.pack_lists_and_flags(job.lists_for_peers(bounds_all), job.flag, shard)
+            mark("col_reduce")
+            lists, flag = sharding.unpack_lists_and_flags(sharding.exchange_lists(packed), shard, kk)
+            mark("exchange")
+            job.finish(z_all, lists, flag, res)
+            mark("finish")
             tiles_step[0] = job.tiles
         else:
-            session = engine.TopkSession(z_shard, nq, shard.row0, args.k, min_sim, slots=slots, workspace=workspace)
+            session = engine.TopkSession(z_shard, nq, shard.row0, kk, ms_sweep, slots=slots, workspace=workspace)
             if timed:
                 ev[0].record()
             if own_matrix is not None and world > 1:  # own columns: overlaps the all-gather
                 session.accumulate_own_matrix(own_matrix)
             else:
                 session.accumulate((z_shard, own[1], own[0]))
+            mark("own")
             if work is not None:
                 work.wait()
+                mark("gather_wait")
                 session.accumulate((z_all[after[0]:], after[1], after[0]), (z_all, before[1], before[0]))
-            session.finish(out)
+                mark("rest")
+            session.finish(res)
+            mark("finish")
             tiles_step[0] = session.tiles
         if timed:
             ev[1].record()
-        comp = engine.component_scores(z_all, offsets, scales, out.idx, q_row0=shard.row0, n=args.n)
+        mark("sweeps")
+        if path_exact:
+            top = engine.exact_topk(z_all, src_all, offsets, groups, gw, args.k, min_sim, n=args.n, q_row0=shard.row0,
+                                    nq=nq, cand=res)
+            rerank_stats.update(top.stats)
+            result = top
+        else:
+            result = engine.component_scores(z_all, offsets, scales, res.idx, q_row0=shard.row0, n=args.n)
+        mark("rerank" if path_exact else "k5")
         if timed:
             ev[1].synchronize()
             kernel_ms.append(ev[0].elapsed_time(ev[1]))
-        return comp
+            phase_marks.append(marks)
+        return result
 
     def barrier():
         torch.cuda.synchronize()
@@ -392,8 +464,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    out_k = out if kc == args.k else new_out(args.k)
     if symmetric and world > 1:
-        step(False)  # untimed: the first use of the int64 all-gather, the all-to-all and the max-reduction
+        step(False)  # untimed: the first use of the int64 all-gather and the all-to-all
     for _ in range(args.warmup):
         step(False)
     barrier()
@@ -402,14 +475,46 @@ def main():
         step(True)
     barrier()
     elapsed = time.perf_counter() - t0
+    tiles_main = tiles_step[0]  # of the timed path (the comparison steps below run another K)
     if world > 1:
         elapsed = max_over_ranks(elapsed)
         kernel_avg_ms = max_over_ranks(sum(kernel_ms) / max(len(kernel_ms), 1))
     else:
         kernel_avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
 
+    # per-phase device time (HIP events on the compute stream), averaged over the timed steps, and
+    # for several ranks the maximum over the ranks of every phase: where a step's time goes
+    phases = {}
+    for marks in phase_marks:
+        for (_, e0), (name, e1) in zip(marks, marks[1:]):
+            phases[name] = phases.get(name, 0.0) + e0.elapsed_time(e1) / len(phase_marks)
+    if world > 1:
+        phases = {name: max_over_ranks(v) for name, v in phases.items()}
+    phases = {f"{name}_ms": round(v, 4) for name, v in phases.items()}
+
+    # the fp32-only step (lists of the fp32 scores + K5), timed the same way on a few steps, beside the exact one
+    fp32_step = None
+    if exact:
+        n_cmp = max(1, min(args.steps, 8))
+        if world > 1 and symmetric and kc != args.k and not sharding.symmetric_route_fits(world, args.k, ld):
+            n_cmp = 0
+        if n_cmp:
+            step(False, path_exact=False)
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(n_cmp):
+                step(False, path_exact=False)
+            barrier()
+            el = time.perf_counter() - t1
+            if world > 1:
+                el = max_over_ranks(el)
+            fp32_step = {"ms_per_step": el / n_cmp * 1e3, "value": float(args.n) * float(args.n) * n_cmp / el,
+                         "steps": n_cmp, "note": "K1 -> fp32 lists of K -> K5 (fp32 per-block scores): no float64 "
+                                                  "re-rank, indices exact only where fp32 separates the scores"}
+
     if args.check and nq:
-        ref = engine.TopkSession(z_shard, nq, shard.row0, args.k, min_sim)
+        step(False)  # the candidates of the timed path once more: `out` must hold them
+        ref = engine.TopkSession(z_shard, nq, shard.row0, kc, sweep_min)
         ref.accumulate((z_shard, own[1], own[0]))
         if world > 1:
             ref.accumulate((z_all[after[0]:], after[1], after[0]), (z_all, before[1], before[0]))
@@ -427,21 +532,23 @@ def main():
     # multiplied like any other), over the HIP-event time around them.
     per_rank_rows = shard.per_rank if world > 1 else nq
     algorithmic = 2.0 * per_rank_rows * args.n * args.d
-    executed = 2.0 * tiles_step[0] * 128.0 * 128.0 * ld
+    executed = 2.0 * tiles_main * 128.0 * 128.0 * ld
     achieved = executed / (kernel_avg_ms * 1e-3) / 1e12
     effective = algorithmic / (kernel_avg_ms * 1e-3) / 1e12
     plain_tiles = ((nq + 127) // 128) * ((args.n + 127) // 128)
     workload = (f"N={args.n} shows x D={args.d} fp32 ({'genre32|text%d|meta32 hybrid-like' % (args.d - 64) if args.data == 'hybrid' else 'dense gaussian'}), "
                 f"K={args.k}, min_similarity={min_sim}")
+    if exact:
+        workload += f" (sweep collects {kc} candidates per show for the float64 re-rank)"
     traffic = None
     tf = ROOT / "profiles" / "traffic.json"
     if tf.exists():
         try:
-            key = f"n{args.n}_d{args.d}_k{args.k}_{args.data}_g{world}" + ("_sym" if symmetric else "")
+            key = f"n{args.n}_d{args.d}_k{kc}_{args.data}_g{world}" + ("_sym" if symmetric else "")
             traffic = json.loads(tf.read_text()).get(key)
         except Exception:
             traffic = None
-    share = tiles_step[0] / plain_tiles if plain_tiles else None  # of the ordered pairs, really computed
+    share = tiles_main / plain_tiles if plain_tiles else None  # of the ordered pairs, really computed
     line = {
         "metric": "show-pairs/sec (all-pairs cosine + per-row top-K)",
         "value": pairs / elapsed,
@@ -461,6 +568,13 @@ def main():
                    "sweep": "symmetric: every unordered pair of shows computed once, both shows' lists fed from it; "
                             "roofline.achieved counts the flops executed" if symmetric else "plain: every ordered pair computed"},
         "topk_build_time_s": elapsed / args.steps,
+        "path": ("exact: fp32 sweep for %d candidates per show, float64 re-rank to K=%d from the stored features "
+                 "(reference's float64 order, scores, threshold cut and per-block scores)" % (kc, args.k)) if exact
+                else "fp32: fp32 lists of K + K5",
+        "phases": phases,
+        "rerank": dict(rerank_stats) if exact else None,
+        "fp32_step": fp32_step,
+        "rccl_world": (dist.get_world_size() if world > 1 else 1),
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                      "kernel": ("cosine_topk_dma_kernel<false, 0, false> + <false, 0, true> (own block and half sweep of the "
@@ -482,9 +596,9 @@ def main():
     x_host = None  # --no-cpu-baseline skips both host-side legs (profiling runs)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         x_host = x[:nq].cpu().numpy()
-    if x_host is not None and not args.no_end_to_end:
+    if x_host is not None and not args.no_end_to_end and len(weights) == 3:
         del workspace  # the measurement allocates its own
-        line["end_to_end"] = end_to_end(x_host, offsets, scales, args.k, min_sim, dev)
+        line["end_to_end"] = end_to_end(x_host, offsets, weights, args.k, min_sim, dev)
     if x_host is not None and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(x_host, offsets, weights, args.k, min_sim, args.cpu_seconds)
     if rank == 0:

@@ -395,7 +395,7 @@ def _sym_worker(rank, world, port, n, k, min_sim, ret):
 
             @property
             def flag(self):
-                return torch.zeros((1,), dtype=torch.int32)
+                return torch.zeros((4 + self.sh.padded_total,), dtype=torch.int32)
 
             def finish(self, z_all, recv, flag):
                 assert int(flag.max().item()) == 0
@@ -565,3 +565,31 @@ def test_catalogue_route_is_bounded_by_available_memory():
         engine.choose_catalogue_route(9 * gib, 2 * gib, 1 * gib)
     assert engine.candidate_count(20) == 28 and engine.candidate_count(22) == 30
     assert engine.candidate_count(23) == 39 and engine.candidate_count(90) == 100 and engine.candidate_count(100) == 100
+
+
+@pytest.mark.parametrize("world,per,k", [(2, 5, 3), (3, 4, 2), (8, 7, 20)])
+def test_packed_exchange_carries_lists_and_overflow_words(pkg, world, per, k):
+    """sharding.pack_lists_and_flags / unpack_lists_and_flags: what every rank unpacks after the
+    all-to-all (simulated by indexing) are the lists its peers found for its shows and the
+    element-wise maximum of their overflow words for those shows."""
+    import torch
+
+    from tvbingefriend_recommendation_service_amd import sharding
+
+    gen = torch.Generator().manual_seed(world * 100 + per)
+    shards = [sharding.Shard(r, world, world * per - 1, per, r * per, per if r < world - 1 else per - 1) for r in range(world)]
+    sends = [torch.randint(-2**62, 2**62, (world, per, k), generator=gen, dtype=torch.int64) for _ in range(world)]
+    flags = [torch.randint(0, 2, (4 + world * per,), generator=gen, dtype=torch.int32) * (torch.rand(4 + world * per, generator=gen) < 0.3)
+             for _ in range(world)]
+    packed = [sharding.pack_lists_and_flags(sends[r], flags[r].to(torch.int32), shards[r]) for r in range(world)]
+    for r in range(world):
+        recv = torch.stack([packed[p][r] for p in range(world)])  # the all-to-all
+        lists, flag = sharding.unpack_lists_and_flags(recv, shards[r], k)
+        assert lists.shape == (world, per, k) and lists.stride(1) == k and lists.stride(2) == 1
+        for p in range(world):
+            assert torch.equal(lists[p], sends[p][r])
+        want = torch.stack([flags[p][4 + r * per : 4 + (r + 1) * per] for p in range(world)]).max(dim=0).values.to(torch.int32)
+        assert torch.equal(flag[4 + r * per : 4 + (r + 1) * per], want)
+        assert int(flag[0]) == int(want.max())
+        rest = torch.cat([flag[1 : 4 + r * per], flag[4 + (r + 1) * per :]])
+        assert int(rest.abs().max()) == 0

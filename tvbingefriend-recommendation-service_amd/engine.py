@@ -902,7 +902,7 @@ class TopkSession:
     def finish(self, out: TopK | None = None, *, extra: torch.Tensor | None = None, gate=None,
                alt: tuple[int, int] | None = None, slots: int | None = None) -> TopK:
         """Merge the partial lists of slots 0 .. slots-1 (default: all used) and of ``extra``
-        (int64 keys, (lists, rows >= nq, k) contiguous).  With ``gate`` (overflow words as for
+        (int64 keys, (lists, rows >= nq, k), every list contiguous, any distance between lists).  With ``gate`` (overflow words as for
         accumulate) and ``alt=(first, count)`` a flagged row merges slots first .. first+count-1 alone."""
         if out is None:
             out = TopK(torch.empty((self.nq, self.k), dtype=torch.int32, device=self.dev),
@@ -914,9 +914,10 @@ class TopkSession:
         n_extra, stride, extra_ptr = 0, 0, None
         if extra is not None and extra.numel():
             _require_cuda(extra, "extra", dtype=torch.int64)
-            if extra.dim() != 3 or not extra.is_contiguous() or extra.shape[2] != self.k or extra.shape[1] < self.nq:
-                raise ValueError("extra must be a contiguous (lists, rows >= nq, k) int64 tensor")
-            n_extra, stride, extra_ptr = extra.shape[0], extra.shape[1] * self.k, extra.data_ptr()
+            if (extra.dim() != 3 or extra.shape[2] != self.k or extra.shape[1] < self.nq or extra.stride(2) != 1
+                    or extra.stride(1) != self.k or (extra.shape[0] > 1 and extra.stride(0) < extra.shape[1] * self.k)):
+                raise ValueError("extra must be (lists, rows >= nq, k) int64 with contiguous lists")
+            n_extra, stride, extra_ptr = extra.shape[0], extra.stride(0), extra.data_ptr()
         gate_ptr, alt_first, alt_slots = None, 0, 0
         if gate is not None:
             _require_cuda(gate, "gate", dtype=torch.int32)

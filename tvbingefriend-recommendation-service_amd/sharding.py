@@ -335,6 +335,31 @@ def exchange_lists(send: torch.Tensor, group=None) -> torch.Tensor:
     return torch.stack([parts[p][rank] for p in range(world)]).to(send.device)
 
 
+def pack_lists_and_flags(send: torch.Tensor, flags: torch.Tensor, shard: Shard) -> torch.Tensor:
+    """One all-to-all payload per peer: the K-lists found here for the peer's shows followed by the
+    overflow words of those shows (``flags``: the [4 + padded_total] int32 words of a column side).
+    (world, per_rank, k) int64 + int32 words -> (world, per_rank * k + ceil(per_rank / 2)) int64."""
+    W, P = shard.world, shard.per_rank
+    words = flags[4 : 4 + W * P].reshape(W, P)
+    if P % 2:
+        words = torch.nn.functional.pad(words, (0, 1))
+    return torch.cat([send.reshape(W, -1), words.contiguous().view(torch.int64)], dim=1)
+
+
+def unpack_lists_and_flags(recv: torch.Tensor, shard: Shard, k: int):
+    """What the peers sent here (pack_lists_and_flags, after the all-to-all): the lists as a
+    (world, per_rank, k) view and the overflow words of THIS rank's shows, max-reduced over the
+    senders, placed in a [4 + padded_total] int32 tensor ([0] = some show of this rank is flagged).
+    A rank re-runs only its own rows, so it needs no other rank's words."""
+    W, P = shard.world, shard.per_rank
+    lists = recv[:, : P * k].unflatten(1, (P, k))
+    words = recv[:, P * k :].contiguous().view(torch.int32)[:, :P].max(dim=0).values
+    flag = torch.zeros(4 + W * P, dtype=torch.int32, device=recv.device)
+    flag[4 + shard.rank * P : 4 + (shard.rank + 1) * P] = words
+    flag[0] = words.max() if P else 0
+    return lists, flag
+
+
 def reduce_flag(flag: torch.Tensor, group=None) -> torch.Tensor:
     """element-wise max over the ranks of a small tensor (a copy; the input is left alone)."""
     if _via_host(flag, group):
@@ -350,8 +375,8 @@ def sharded_topk_symmetric(x_shard: torch.Tensor, offsets, scales, shard: Shard,
                            group=None, normalize_fn=None, job_fn=None):
     """sharded_topk with every block between two shards computed once: normalise own rows ->
     all-gather of Z (asynchronous) -> own block -> all-gather of the per-row bounds -> blocks of the
-    cyclically following half of the shards, rows and columns fed -> all-to-all of the column-side
-    lists (world x per_rank x k keys) -> merge.  Same lists as sharded_topk, bit for bit.
+    cyclically following half of the shards, rows and columns fed -> one all-to-all of the column-side
+    lists (world x per_rank x k keys) with the overflow words of the receiver's shows -> merge.  Same lists as sharded_topk, bit for bit.
     Needs a row length that is a multiple of 64 (the engine raises otherwise) and a K for which one
     merge can take the rank's own lists plus one per rank: symmetric_route_fits()."""
     if normalize_fn is None:
@@ -389,7 +414,7 @@ def sharded_topk_symmetric(x_shard: torch.Tensor, offsets, scales, shard: Shard,
     if work is not None:
         work.wait()
     job.phase_half(z_all, bounds_all)
-    send = job.lists_for_peers(bounds_all)
-    flag = reduce_flag(job.flag, group)
-    recv = exchange_lists(send, group)
-    return job.finish(z_all, recv, flag), z_all
+    # one all-to-all carries the column-side lists and the overflow words of the receiver's shows
+    packed = pack_lists_and_flags(job.lists_for_peers(bounds_all), job.flag, shard)
+    lists, flag = unpack_lists_and_flags(exchange_lists(packed, group), shard, k)
+    return job.finish(z_all, lists, flag), z_all
