@@ -87,3 +87,43 @@ def synthetic_shows(n: int, seed: int):
             }
         )
     return pd.DataFrame(rows)
+
+
+def write_feature_files(path, n: int, seed: int = 7, d_text: int = 500) -> dict:
+    """A synthetic catalogue in the reference's on-disk form (scripts/compute_features.py:115-129:
+    genre multi-hot int64, TF-IDF CSR float64 with unit rows, platform one-hot of 21 float64, type
+    dummies bool, language one-hot of 6 float64) plus shows_metadata.csv; returns the arrays."""
+    import scipy.sparse as sp
+
+    rng = np.random.default_rng(seed)
+    genre = (rng.random((n, 24)) < 0.1).astype(np.int64)
+    nnz_per_row = rng.integers(8, 48, size=n)
+    nnz_per_row[rng.random(n) < 0.02] = 0  # shows without a summary: all-zero TF-IDF rows
+    indptr = np.concatenate([[0], np.cumsum(nnz_per_row)])
+    # distinct sorted columns per row: the smallest keys of a random key per (row, column)
+    order = np.argsort(rng.random((n, d_text)), axis=1)[:, :48] if n else np.empty((0, 48), int)
+    keep = np.arange(48)[None, :] < nnz_per_row[:, None]
+    cols = np.sort(np.where(keep, order, d_text), axis=1)[keep] if n else np.empty(0, int)
+    vals = np.abs(rng.standard_normal(indptr[-1])) + 0.05
+    text = sp.csr_matrix((vals, cols, indptr), shape=(n, d_text), dtype=np.float64)
+    norms = np.sqrt(np.asarray(text.multiply(text).sum(axis=1)).ravel())
+    norms[norms == 0] = 1.0
+    text = sp.csr_matrix(sp.diags(1.0 / norms) @ text)
+
+    def one_hot(width, dtype, p=None):
+        out = np.zeros((n, width), dtype=dtype)
+        out[np.arange(n), rng.choice(width, size=n, p=p)] = 1
+        return out
+
+    p_platform = np.r_[np.full(20, 0.7 / 20), 0.3]
+    feats = {"genre_features": genre, "text_features": text,
+             "platform_features": one_hot(21, np.float64, p_platform),
+             "type_features": one_hot(8, bool), "language_features": one_hot(6, np.float64, [0.6, 0.1, 0.1, 0.08, 0.07, 0.05])}
+    for key, value in feats.items():
+        if sp.issparse(value):
+            sp.save_npz(path / f"{key}.npz", value, compressed=False)
+        else:
+            np.save(path / f"{key}.npy", value)
+    ids = np.arange(1, n + 1) * 3 + 11
+    (path / "shows_metadata.csv").write_text("id,name\n" + "\n".join(f"{i},show {i}" for i in ids) + "\n")
+    return feats

@@ -501,3 +501,30 @@ def test_concurrent_calls_from_two_threads_on_two_streams(pkg, device):
         t.join(timeout=120)
     assert not any(t.is_alive() for t in threads), "a worker did not finish"
     assert not errors, errors
+
+
+def test_populate_on_two_ranks_equals_single_gpu(pkg, device, tmp_path):
+    """compute_and_store_similarities(gpus=2): two fresh rank processes (gloo, sharing this GPU:
+    the exchange goes through host memory) read the feature files, each builds and sweeps its shard,
+    rank 0 hands the gathered lists back -- the sink receives exactly the records of the single-GPU
+    call (scripts/populate_database.py:85-259 with the shows split over two ranks)."""
+    from tvbingefriend_recommendation_service_amd.scripts import populate_database as pd_amd
+
+    g = load_golden("plumbing_100")
+    _write_feature_dir(tmp_path, g)
+    one, two = pd_amd.MemorySimilaritySink(), pd_amd.MemorySimilaritySink()
+    s1 = pd_amd.compute_and_store_similarities(tmp_path, 0.4, 0.5, 0.1, repo=one)
+    s2 = pd_amd.compute_and_store_similarities(tmp_path, 0.4, 0.5, 0.1, repo=two, gpus=2, backend="gloo")
+    assert s1["total_records"] == s2["total_records"] > 0
+    assert one.records == two.records
+    # a larger catalogue whose shards take the symmetric sharded sweep with stored own blocks
+    from synth import write_feature_files
+
+    big = tmp_path / "big"
+    big.mkdir()
+    write_feature_files(big, 6000, seed=3)
+    one, two = pd_amd.ColumnarSimilaritySink(), pd_amd.ColumnarSimilaritySink()
+    pd_amd.compute_and_store_similarities(big, repo=one)
+    pd_amd.compute_and_store_similarities(big, repo=two, gpus=3, backend="gloo")
+    for c in pd_amd.TABLE_COLUMNS:
+        assert np.array_equal(one.table[c], two.table[c]), c

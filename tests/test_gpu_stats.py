@@ -219,3 +219,41 @@ def test_band_route_at_100k_verified_by_counting(pkg, device):
     assert got[2] == mn and got[3] == mx
     mean = s / count
     assert abs(got[0] - mean) <= 1e-11 and abs(got[1] - np.sqrt(sq / count - mean * mean)) <= 1e-10, (got, mean)
+
+
+def test_compute_similarities_script_at_100k_takes_the_matrix_free_route(pkg, device, tmp_path, caplog):
+    """scripts/compute_similarities.py (reference :84-133, :180-262) at a size whose four float64
+    matrices (320 GB) cannot exist: main() reads the feature files, takes the matrix-free route by
+    itself, logs the four statistics blocks and returns them with the top-20 lists.  The hybrid
+    block equals tvbf_gram_stats_f32 called directly on the same Z."""
+    import logging
+    import time
+
+    import torch
+
+    from synth import write_feature_files
+    from tvbingefriend_recommendation_service_amd import engine, features as feat
+    from tvbingefriend_recommendation_service_amd.scripts import compute_similarities as cs
+
+    n = 100_000
+    feats = write_feature_files(tmp_path, n, seed=7)
+    assert cs.matrix_bytes(feats) > cs.MATRIX_BYTES_LIMIT
+    t0 = time.perf_counter()
+    with caplog.at_level(logging.INFO):
+        out = cs.main(["--input-dir", str(tmp_path)])
+    wall = time.perf_counter() - t0
+    assert set(out) == {"statistics", "top_neighbours"}
+    log = caplog.text
+    assert "SIMILARITY STATISTICS" in log and "Matrix-free route" in log
+    for name in ("genre_similarity", "text_similarity", "metadata_similarity", "hybrid_similarity"):
+        assert f"{name}:" in log and set(out["statistics"][name]) == {"mean", "std", "min", "max", "median"}
+    top = out["top_neighbours"]
+    assert top.idx.shape == (n, 20) and top.score.dtype == np.float64 and int(top.count.max()) == 20
+    sources, layout = feat.block_sources(feats, 0.4, 0.5, 0.1, "computer")
+    z = engine.assemble_normalize(engine.upload_sources(sources, device), n, layout.offsets, layout.scales())
+    direct = engine.gram_stats(z).cpu().numpy()
+    got = out["statistics"]["hybrid_similarity"]
+    assert [got[q] for q in ("mean", "std", "min", "max", "median")] == direct.tolist()
+    with pytest.raises(ValueError, match="no similarity matrices"):
+        cs.save_similarities(out, tmp_path / "out", save_to_disk=True)
+    print(f"compute_similarities.main at n={n}: {wall:.2f} s wall (files -> statistics + top-20), hybrid {got}")

@@ -105,6 +105,19 @@ def upload_sources(sources, device) -> list:
     return out
 
 
+def slice_sources(sources, row0: int, rows: int) -> list:
+    """The device sources restricted to shows row0 .. row0 + rows (views, nothing copied): dense
+    blocks by rows, CSR blocks by their slice of indptr (its entries keep pointing into the whole
+    indices / data arrays)."""
+    out = []
+    for s in sources:
+        if isinstance(s, DenseSource):
+            out.append(DenseSource(s.data[row0:row0 + rows], s.z_col))
+        else:
+            out.append(CsrSource(s.indptr[row0:row0 + rows + 1], s.indices, s.data, s.width, s.z_col))
+    return out
+
+
 def sources_rows(sources) -> int:
     """Number of shows the device sources describe."""
     s = sources[0]

@@ -212,7 +212,7 @@ class SimilarityComputer:
         return [self.genre_weight / total, self.text_weight / total, self.metadata_weight / total]
 
     def topk(self, features: dict, k: int = 20, min_similarity: float = 0.1,
-             variant: str = "computer") -> TopKResult:
+             variant: str = "computer", group=None) -> TopKResult:
         """Top-k hybrid neighbours of every show straight from the feature blocks.
 
         ``variant`` selects which of the reference's two definitions is followed:
@@ -224,9 +224,17 @@ class SimilarityComputer:
         threshold; their scores are then recomputed in float64 from the stored arrays, so the
         order, the scores and the ``score < min_similarity`` cut are the reference's own float64
         decisions (scripts/populate_database.py:190-218); equal float64 scores go by index.
+
+        ``group``: a torch.distributed process group (or True for the default group) whose ranks
+        all make this call with the same features -- one process per GPU.  Every rank builds the
+        normalised rows of its own shard, one all-gather gives every rank the whole matrix, the
+        rank computes and re-ranks the lists of its own rows, and the lists are gathered: every
+        rank returns the whole result, identical to the single-GPU call's.
         """
         from .. import engine
 
+        if group is not None:
+            return self._topk_sharded(features, k, min_similarity, variant, None if group is True else group)
         # the stored arrays go to the device as they are (CSR text stays CSR); Z is built there
         dev_sources, layout, n = self._device_sources(features, variant)
         norms = engine.block_norms(dev_sources, n, layout.offsets)  # raises on NaN / infinity, as sklearn does
@@ -244,3 +252,40 @@ class SimilarityComputer:
         self.last_topk_stats = dict(top.stats)
         return TopKResult(top.idx.cpu().numpy(), top.score.cpu().numpy(), top.count.cpu().numpy(),
                           top.comp.cpu().numpy())
+
+    def _topk_sharded(self, features: dict, k: int, min_similarity: float, variant: str, group) -> TopKResult:
+        """:meth:`topk` as one rank of a row-sharded job (scripts/populate_database.py:170-218 with the
+        shows split over the ranks).  The symmetric sharded sweep when the shape allows it (every
+        block between two shards computed by one of them), else the plain sharded sweep."""
+        import torch
+        import torch.distributed as dist
+
+        from .. import engine, sharding
+
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        dev_sources, layout, n = self._device_sources(features, variant)
+        if min(layout.weights) < 0:
+            raise ValueError("negative similarity weights are served by the single-GPU call only")
+        dev = dev_sources[0].data.device
+        norms = engine.block_norms(dev_sources, n, layout.offsets)
+        sh = sharding.shard_bounds(n, world, rank)
+        ld = engine.padded_ld(layout.d)
+        z_shard = torch.zeros((sh.per_rank, ld), dtype=torch.float32, device=dev)
+        if sh.rows:  # only this rank's rows are assembled here; the others arrive with the all-gather
+            engine.assemble_normalize(engine.slice_sources(dev_sources, sh.row0, sh.rows), sh.rows, layout.offsets,
+                                      layout.scales(), out=z_shard[: sh.rows])
+        kc = engine.candidate_count(k)
+        floor = min_similarity - engine.THRESHOLD_BAND
+        if sharding.symmetric_route_fits(world, kc, ld):
+            cand, z_all = sharding.sharded_topk_symmetric_z(z_shard, sh, kc, floor, group=group)
+        else:
+            cand, z_all = sharding.sharded_topk_z(z_shard, sh, kc, floor, group=group)
+        top = engine.exact_topk(z_all, dev_sources, layout.offsets, layout.groups, self.group_weights(variant), k,
+                                min_similarity, n=n, q_row0=sh.row0, nq=sh.rows, cand=cand, norms=norms)
+        self.last_topk_stats = dict(top.stats)
+        via_host = dist.get_backend(group) == "gloo"  # gloo: CPU tensors only
+        parts = []
+        for t in (top.idx, top.score, top.count, top.comp):
+            t = t.cpu() if via_host else t
+            parts.append(sharding.gather_lists(t, sh, group).cpu().numpy())
+        return TopKResult(*parts)

@@ -51,28 +51,63 @@ def load_features(input_dir: Path) -> dict:
     return features
 
 
-def compute_similarities(features: dict, genre_weight: float = 0.4, text_weight: float = 0.5,
-                         metadata_weight: float = 0.1) -> dict:
-    """All four similarity matrices plus the statistics log block."""
-    logger.info("=" * 70)
-    logger.info("COMPUTING SIMILARITIES")
-    logger.info("=" * 70)
-    computer = SimilarityComputer(
-        genre_weight=genre_weight, text_weight=text_weight, metadata_weight=metadata_weight
-    )
-    similarities = computer.compute_all_similarities(features)
+# The reference holds four dense float64 n x n matrices at once (32 n^2 bytes: ~205 GB at 80,000
+# shows, scripts/compute_similarities.py:155).  Above this many bytes the script takes the
+# matrix-free route: the statistics block from the features (one sweep per matrix, nothing stored)
+# and the top-K neighbour lists instead of matrices.
+MATRIX_BYTES_LIMIT = 8 << 30
 
+
+def matrix_bytes(features: dict) -> int:
+    n = int(features["genre_features"].shape[0])
+    return 32 * n * n
+
+
+def _log_statistics(all_stats: dict) -> None:
     logger.info("\n" + "=" * 70)
     logger.info("SIMILARITY STATISTICS")
     logger.info("=" * 70)
     for sim_name in ["genre_similarity", "text_similarity", "metadata_similarity", "hybrid_similarity"]:
-        stats = computer.get_similarity_statistics(similarities[sim_name])
+        stats = all_stats[sim_name]
         logger.info(f"\n{sim_name}:")
         logger.info(f"  Mean: {stats['mean']:.4f}")
         logger.info(f"  Std:  {stats['std']:.4f}")
         logger.info(f"  Min:  {stats['min']:.4f}")
         logger.info(f"  Max:  {stats['max']:.4f}")
         logger.info(f"  Median: {stats['median']:.4f}")
+
+
+def compute_similarities(features: dict, genre_weight: float = 0.4, text_weight: float = 0.5,
+                         metadata_weight: float = 0.1, matrices: bool | None = None, top_n: int = 20,
+                         min_similarity: float = 0.1) -> dict:
+    """All four similarity matrices plus the statistics log block
+    (scripts/compute_similarities.py:84-133 of the reference).
+
+    ``matrices`` False -- or None and 32 n^2 bytes above ``MATRIX_BYTES_LIMIT`` -- takes the
+    matrix-free route for catalogues whose matrices cannot be held: the same statistics block,
+    computed from the features without storing a matrix, and a dict
+    ``{"statistics": {...four blocks...}, "top_neighbours": TopKResult}`` (the ``top_n`` best
+    neighbours per show above ``min_similarity``: what the pipeline stores downstream,
+    scripts/populate_database.py:309-317) instead of the four n x n arrays."""
+    logger.info("=" * 70)
+    logger.info("COMPUTING SIMILARITIES")
+    logger.info("=" * 70)
+    computer = SimilarityComputer(
+        genre_weight=genre_weight, text_weight=text_weight, metadata_weight=metadata_weight
+    )
+    if matrices is None:
+        matrices = matrix_bytes(features) <= MATRIX_BYTES_LIMIT
+    if not matrices:
+        n = int(features["genre_features"].shape[0])
+        logger.info(f"Matrix-free route: {n} shows ({matrix_bytes(features) / 2**30:.1f} GiB of float64 matrices not formed)")
+        all_stats = computer.get_feature_statistics(features)
+        _log_statistics(all_stats)
+        top = computer.topk(features, k=top_n, min_similarity=min_similarity)
+        logger.info(f"✓ Top-{top_n} neighbours of {n} shows: {int(top.count.sum())} pairs at or above {min_similarity}")
+        return {"statistics": all_stats, "top_neighbours": top}
+    similarities = computer.compute_all_similarities(features)
+    _log_statistics({name: computer.get_similarity_statistics(similarities[name]) for name in
+                     ["genre_similarity", "text_similarity", "metadata_similarity", "hybrid_similarity"]})
     return similarities
 
 
@@ -85,6 +120,9 @@ def save_similarities(similarities: dict, output_dir: Path, save_to_disk: bool =
         logger.info("⊘ Skipping similarity matrix storage (storage optimization)")
         logger.info("  Use --save-similarities flag to save for analysis/debugging")
         return
+    if "top_neighbours" in similarities:
+        raise ValueError("the matrix-free route forms no similarity matrices to save "
+                         "(drop --no-matrices, or raise MATRIX_BYTES_LIMIT, for catalogues whose matrices fit)")
     output_dir = Path(output_dir)
     output_dir.mkdir(parents=True, exist_ok=True)
     total_size = 0
@@ -106,6 +144,11 @@ def main(argv=None):
     parser.add_argument("--text-weight", type=float, default=0.5)
     parser.add_argument("--metadata-weight", type=float, default=0.1)
     parser.add_argument("--save-similarities", action="store_true")
+    parser.add_argument("--no-matrices", action="store_true",
+                        help="statistics and top-N neighbours straight from the features, no n x n matrix "
+                             "(taken by itself when the matrices would exceed MATRIX_BYTES_LIMIT)")
+    parser.add_argument("--top-n", type=int, default=20)
+    parser.add_argument("--min-similarity", type=float, default=0.1)
     args = parser.parse_args(argv)
 
     logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(name)s - %(levelname)s - %(message)s")
@@ -117,7 +160,8 @@ def main(argv=None):
         features = load_features(Path(args.input_dir))
         similarities = compute_similarities(
             features=features, genre_weight=args.genre_weight, text_weight=args.text_weight,
-            metadata_weight=args.metadata_weight,
+            metadata_weight=args.metadata_weight, matrices=False if args.no_matrices else None,
+            top_n=args.top_n, min_similarity=args.min_similarity,
         )
         save_similarities(similarities, Path(args.output_dir), save_to_disk=args.save_similarities)
         logger.info("✓ SIMILARITY COMPUTATION COMPLETE")

@@ -153,18 +153,115 @@ def write_table_csv(table: dict, path, header: bool = True) -> int:
 
 def compute_top_neighbours(features: dict, genre_weight: float = 0.4, text_weight: float = 0.5,
                            metadata_weight: float = 0.1, top_n_per_show: int = 20,
-                           min_similarity: float = 0.1, device=None) -> TopKResult:
+                           min_similarity: float = 0.1, device=None, group=None) -> TopKResult:
     """Columnar result of the production path (metadata = mean of three cosines,
-    raw weights: populate_database.py:184-192) for array-native sinks."""
+    raw weights: populate_database.py:184-192) for array-native sinks.  ``group``: the ranks of a
+    row-sharded job (see SimilarityComputer.topk); every rank returns the whole result."""
     sc = SimilarityComputer(genre_weight=genre_weight, text_weight=text_weight,
                             metadata_weight=metadata_weight, device=device)
-    return sc.topk(features, k=top_n_per_show, min_similarity=min_similarity, variant="populate")
+    return sc.topk(features, k=top_n_per_show, min_similarity=min_similarity, variant="populate", group=group)
+
+
+RANK_WORKER = ("import tvbf_amd; from tvbingefriend_recommendation_service_amd.scripts.populate_database "
+               "import _rank_main; _rank_main()")
+
+
+def _rank_main() -> None:
+    """Body of one rank process started by :func:`compute_top_neighbours_on_gpus`: joins the process
+    group, loads the feature files, takes part in the sharded computation; rank 0 leaves the
+    result in the file named by TVBF_RESULT."""
+    import json
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    cfg = json.loads(os.environ["TVBF_JOB"])
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dev = torch.device(f"cuda:{int(os.environ['LOCAL_RANK']) % torch.cuda.device_count()}")
+    torch.cuda.set_device(dev)
+    if cfg["backend"] == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group("gloo")
+    try:
+        features = load_features(Path(cfg["input_dir"]))
+        result = compute_top_neighbours(features, cfg["genre_weight"], cfg["text_weight"], cfg["metadata_weight"],
+                                        cfg["top_n_per_show"], cfg["min_similarity"], device=dev, group=True)
+        if rank == 0:
+            np.savez(os.environ["TVBF_RESULT"], idx=result.idx, score=result.score, count=result.count,
+                     comp=result.comp)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def compute_top_neighbours_on_gpus(input_dir: Path, gpus: int, genre_weight: float = 0.4, text_weight: float = 0.5,
+                                   metadata_weight: float = 0.1, top_n_per_show: int = 20,
+                                   min_similarity: float = 0.1, backend: str = "nccl", timeout: float = 3600.0) -> TopKResult:
+    """The production path row-sharded over ``gpus`` GPUs of this node: starts one fresh process per
+    GPU (rank r on GPU r, rendezvous on 127.0.0.1 -- children of this process, which itself never
+    touches a GPU for it), every rank reads the feature files, builds its shard of the normalised
+    matrix, takes part in one all-gather and computes the lists of its rows; rank 0 hands the gathered
+    result back through a temporary file.  ``backend`` "gloo" lets several ranks share one GPU
+    (rehearsal: the exchange goes through host memory)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    import tempfile
+    import time
+
+    if gpus < 2:
+        raise ValueError("gpus must be at least 2 (the single-GPU path needs no ranks)")
+    root = str(Path(__file__).resolve().parents[2])
+    with socket.socket() as sck:
+        sck.bind(("127.0.0.1", 0))
+        port = sck.getsockname()[1]
+    job = json.dumps({"input_dir": str(input_dir), "genre_weight": genre_weight, "text_weight": text_weight,
+                      "metadata_weight": metadata_weight, "top_n_per_show": top_n_per_show,
+                      "min_similarity": min_similarity, "backend": backend})
+    with tempfile.TemporaryDirectory() as tmp:
+        result_path = str(Path(tmp) / "result.npz")
+        procs = []
+        for r in range(gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(gpus), LOCAL_WORLD_SIZE=str(gpus),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TVBF_JOB=job, TVBF_RESULT=result_path,
+                       PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+            procs.append(subprocess.Popen([sys.executable, "-c", RANK_WORKER], env=env))
+        deadline = time.time() + timeout
+        failed = None
+        while any(p.poll() is None for p in procs) and failed is None:
+            failed = next((p.returncode for p in procs if p.poll() not in (None, 0)), None)
+            if failed is None and time.time() > deadline:
+                failed = -1
+            time.sleep(0.05)
+        if failed is not None:  # one rank failed (or time ran out): end the others, by their own PIDs
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            raise RuntimeError(f"a rank of the sharded job failed (exit code {failed})")
+        with np.load(result_path) as r:
+            return TopKResult(r["idx"], r["score"], r["count"], r["comp"])
 
 
 def compute_and_store_similarities(input_dir: Path, genre_weight: float = 0.4, text_weight: float = 0.5,
                                    metadata_weight: float = 0.1, top_n_per_show: int = 20,
-                                   min_similarity: float = 0.1, repo=None, clear_existing=None) -> dict:
+                                   min_similarity: float = 0.1, repo=None, clear_existing=None,
+                                   gpus: int | None = None, backend: str = "nccl") -> dict:
     """Compute the top-N neighbours of every show and store them.
+
+    ``gpus`` > 1 shards the shows over that many GPUs of this node.  Inside a launcher's rank
+    (torch.distributed initialised by the caller) the given ranks are used: every rank calls this
+    function, rank 0 alone feeds the sink, the others return the statistics without storing.
+    Otherwise fresh rank processes are started for the computation
+    (:func:`compute_top_neighbours_on_gpus`) and this process feeds the sink.
 
     A sink that also has ``store_similarity_table(table: dict) -> int`` receives the six flat
     columns of :func:`neighbour_table` once instead of record dicts in batches.
@@ -190,8 +287,16 @@ def compute_and_store_similarities(input_dir: Path, genre_weight: float = 0.4, t
     if features["genre_features"].shape[0] != n:
         raise ValueError("shows_metadata.csv and the feature files disagree on the number of shows")
 
+    in_group = False
+    if gpus is not None and gpus > 1:
+        import torch.distributed as dist
+
+        in_group = dist.is_available() and dist.is_initialized()
+        if in_group and dist.get_world_size() != gpus:
+            raise ValueError(f"gpus={gpus} but the process group has {dist.get_world_size()} ranks")
+    store = not in_group or dist.get_rank() == 0  # of a launcher's ranks only rank 0 touches the sink
     db = None
-    if repo is None:  # drop-in inside the reference's own process
+    if repo is None and store:  # drop-in inside the reference's own process
         from tvbingefriend_recommendation_service.models import ShowSimilarity
         from tvbingefriend_recommendation_service.models.database import SessionLocal
         from tvbingefriend_recommendation_service.repos import SimilarityRepository
@@ -203,13 +308,24 @@ def compute_and_store_similarities(input_dir: Path, genre_weight: float = 0.4, t
                 db.query(ShowSimilarity).delete()
                 db.commit()
     try:
-        if clear_existing is not None:
+        if clear_existing is not None and store:
             logger.info("Clearing existing similarities from database...")
             clear_existing()
 
-        result = compute_top_neighbours(features, genre_weight, text_weight, metadata_weight,
-                                        top_n_per_show, min_similarity)
+        if gpus is not None and gpus > 1:
+            if in_group:
+                result = compute_top_neighbours(features, genre_weight, text_weight, metadata_weight,
+                                                top_n_per_show, min_similarity, group=True)
+            else:
+                result = compute_top_neighbours_on_gpus(input_dir, gpus, genre_weight, text_weight, metadata_weight,
+                                                        top_n_per_show, min_similarity, backend=backend)
+        else:
+            result = compute_top_neighbours(features, genre_weight, text_weight, metadata_weight,
+                                            top_n_per_show, min_similarity)
         total_records_stored = 0
+        if not store:  # a rank other than 0 of a launcher's job: rank 0 stores
+            return {"total_records": int(np.minimum(result.count, top_n_per_show).sum()),
+                    "top_n_per_show": top_n_per_show, "min_similarity": min_similarity}
         if hasattr(repo, "store_similarity_table"):  # array-native sink: no per-pair Python objects
             total_records_stored = int(repo.store_similarity_table(neighbour_table(result, show_ids)))
         else:

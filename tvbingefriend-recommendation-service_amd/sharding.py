@@ -100,6 +100,19 @@ def sharded_topk(x_shard: torch.Tensor, offsets, scales, shard: Shard, k: int, m
     if x_shard.shape[0] != shard.per_rank:
         raise ValueError("x_shard must be padded to per_rank rows")
     z_shard = normalize_fn(x_shard, offsets, scales)
+    return sharded_topk_z(z_shard, shard, k, min_similarity, group=group, session_fn=session_fn, collective=collective)
+
+
+def sharded_topk_z(z_shard: torch.Tensor, shard: Shard, k: int, min_similarity: float, group=None, session_fn=None,
+                   collective=None):
+    """:func:`sharded_topk` from the rank's normalised rows ``z_shard`` ((per_rank, ld), padding
+    rows zero) on: all-gather, own columns meanwhile, the rest, merge."""
+    if session_fn is None:
+        from . import engine
+
+        session_fn = engine.TopkSession
+    if z_shard.shape[0] != shard.per_rank:
+        raise ValueError("z_shard must be padded to per_rank rows")
     if collective is None:
         collective = shard.world > 1
     if not collective:
@@ -109,14 +122,21 @@ def sharded_topk(x_shard: torch.Tensor, offsets, scales, shard: Shard, k: int, m
         session.accumulate((z_shard, shard.rows, 0))
         return session.finish(), z_shard
     z_all = torch.empty((shard.padded_total, z_shard.shape[1]), dtype=z_shard.dtype, device=z_shard.device)
-    if z_shard.is_cuda:
+    if _via_host(z_shard, group):  # gloo ranks that use GPUs: through host memory, synchronously
+        host = z_shard.cpu()
+        parts = [torch.empty_like(host) for _ in range(shard.world)]
+        dist.all_gather(parts, host, group=group)
+        z_all.copy_(torch.cat(parts, dim=0))
+        work = None
+    elif z_shard.is_cuda:
         work = dist.all_gather_into_tensor(z_all, z_shard, group=group, async_op=True)
     else:  # gloo: CPU tensors only
         work = dist.all_gather(list(z_all.chunk(shard.world, dim=0)), z_shard, group=group, async_op=True)
     own, after, before = column_pieces(shard)
     session = session_fn(z_shard, shard.rows, shard.row0, k, min_similarity)
     session.accumulate((z_shard, own[1], own[0]))            # runs while the shards travel
-    work.wait()                                              # the current stream now waits for the gather
+    if work is not None:
+        work.wait()                                          # the current stream now waits for the gather
     session.accumulate((z_all[after[0]:], after[1], after[0]), (z_all, before[1], before[0]))
     return session.finish(), z_all
 
@@ -383,10 +403,19 @@ def sharded_topk_symmetric(x_shard: torch.Tensor, offsets, scales, shard: Shard,
         from . import engine
 
         normalize_fn = engine.normalize_blocks
-    job_fn = job_fn or SymmetricShardJob
     if x_shard.shape[0] != shard.per_rank:
         raise ValueError("x_shard must be padded to per_rank rows")
     z_shard = normalize_fn(x_shard, offsets, scales)
+    return sharded_topk_symmetric_z(z_shard, shard, k, min_similarity, group=group, job_fn=job_fn)
+
+
+def sharded_topk_symmetric_z(z_shard: torch.Tensor, shard: Shard, k: int, min_similarity: float, group=None,
+                             job_fn=None):
+    """:func:`sharded_topk_symmetric` from the rank's normalised rows ``z_shard`` ((per_rank, ld),
+    padding rows zero) on."""
+    job_fn = job_fn or SymmetricShardJob
+    if z_shard.shape[0] != shard.per_rank:
+        raise ValueError("z_shard must be padded to per_rank rows")
     z_all = torch.empty((shard.padded_total, z_shard.shape[1]), dtype=z_shard.dtype, device=z_shard.device)
     host_route = _via_host(z_shard, group)
     if host_route:
