@@ -163,3 +163,22 @@ def test_input_validation_matches_sklearn(pkg, device):
         SimilarityComputer(device=device).topk(bad, k=5)
     with pytest.raises(ValueError, match="Input contains infinity"):
         SimilarityComputer(device=device).get_feature_statistics(bad)
+
+
+def test_negative_weights_and_long_lists(pkg, device):
+    """The reference accepts any weights whose sum is not zero (ml/similarity_computer.py:112-124)
+    and any --top-n (scripts/populate_database.py:309-312).  A negative weight goes on the query
+    side of a plain sweep; lists longer than the sweeps keep (K > 100) are selected from float64
+    score rows."""
+    n = 1300
+    feats = hybrid_like_blocks(n, seed=77, d_genre=16, d_text=100, as_features=True)
+    for weights, variant, k, ms in (((0.6, 0.7, -0.3), "computer", 10, 0.05), ((0.5, -0.2, 0.1), "populate", 20, -1.0),
+                                    ((0.4, 0.5, 0.1), "populate", 150, 0.02)):
+        res, st = _exact(pkg, device, feats, weights, variant, k, ms)
+        h, _ = _oracle_hybrid(feats, weights, variant)
+        stats = {}
+        check_topk_against_scores(h, 0, k, ms, res.idx, res.score, res.count, tol=REFINED_TOL, gap=REFINED_GAP,
+                                  what=f"weights {weights} k={k}", stats=stats, f64=True, check_tie_order=False)
+        print(f"weights {weights} {variant} k={k}: {stats}, stages {st}")
+        if k > 100:
+            assert st["scan"] == n and st["candidates"] == 0

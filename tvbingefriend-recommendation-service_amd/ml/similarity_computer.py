@@ -65,17 +65,49 @@ class SimilarityComputer:
     # ---- dense-matrix API (reference: ml/similarity_computer.py:30-130) ----
 
     def _cosine_matrix(self, features_2d) -> np.ndarray:
-        """cosine_similarity(X) as one normalise launch + one MFMA tile sweep."""
+        """cosine_similarity(X) with sklearn's dtype rule (metrics/pairwise.py:51-72): float32 input
+        is computed and returned in float32 -- one normalise launch and one MFMA tile sweep --,
+        everything else in float64: float64 block norms and float64 dot products of the stored
+        values (dense or CSR, nothing densified), one wavefront per pair."""
         import torch
 
         from .. import engine
 
         dev = _torch_device(self.device)
-        out_dtype = np.float32 if getattr(features_2d, "dtype", None) == np.float32 else np.float64
-        x, layout = feat.pack_blocks([features_2d], [1.0])
-        z = engine.normalize_blocks(torch.from_numpy(x).to(dev), layout.offsets, [1.0])
-        s = engine.gram(z)
-        return s.cpu().numpy().astype(out_dtype, copy=False)
+        if getattr(features_2d, "dtype", None) == np.float32:
+            x, layout = feat.pack_blocks([features_2d], [1.0])
+            z = engine.normalize_blocks(torch.from_numpy(x).to(dev), layout.offsets, [1.0])
+            return engine.gram(z).cpu().numpy()
+        if feat._is_sparse(features_2d):
+            a = features_2d.tocsr()
+            if not a.has_canonical_format:
+                a = a.copy()
+                a.sum_duplicates()
+            if a.dtype not in (np.float32, np.float64):
+                a = a.astype(np.float64)
+            n, d = a.shape
+            host = [("csr", a.indptr, a.indices, a.data, d, 0)]
+        else:
+            a = np.asarray(features_2d)
+            if a.ndim != 2:
+                raise ValueError(f"Expected 2D array, got {a.ndim}D array instead")
+            if a.dtype not in (np.float64, np.int64, np.bool_, np.uint8):
+                a = a.astype(np.float64)
+            n, d = a.shape
+            host = [("dense", np.ascontiguousarray(a), 0)]
+        if n == 0 or d == 0:
+            return np.zeros((n, n), dtype=np.float64)
+        sources = engine.upload_sources(host, dev)
+        offsets = [0, d]
+        norms = engine.block_norms(sources, n, offsets)  # NaN / infinity raise ValueError, as sklearn's validation does
+        out = torch.empty((n, n), dtype=torch.float64, device=dev)
+        for r0 in range(0, n, 32768):
+            ids = torch.arange(r0, min(n, r0 + 32768), dtype=torch.int32, device=dev)
+            out[r0:r0 + ids.numel()] = engine.score_rows(sources, n, offsets, [0], [1.0, 0.0, 0.0], norms, ids,
+                                                         exclude_self=False)
+        # (x_i / |x_i|) . x_j / |x_j| and its transpose differ in the last bit: keep one of the two
+        upper = torch.triu(out)
+        return (upper + torch.triu(out, 1).T).cpu().numpy()
 
     def compute_genre_similarity(self, genre_features: np.ndarray) -> np.ndarray:
         logger.info("Computing genre similarity...")
