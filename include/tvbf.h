@@ -22,12 +22,14 @@
  *   - the library allocates no device memory: scratch comes in through the
  *     `workspace` argument, sized by the matching *_workspace_bytes() call;
  *   - no global mutable state: concurrent calls from different host threads
- *     on different streams/devices are safe.  Two exceptions, both stated where
- *     they apply: tvbf_cosine_topk_static_f32 works in a per-device scratch
- *     array that the library owns (overlapping calls on one GPU race), and a
- *     handful of TVBF_* environment variables are read on every call as tuning
- *     and diagnostic switches -- they select among routes that return the same
- *     lists (tested bit for bit), never a different result.
+ *     on different streams/devices are safe.  One exception, stated where it
+ *     applies: tvbf_cosine_topk_static_f32 works in a per-device scratch array
+ *     that the library owns (host threads take turns, a call on another stream
+ *     than the previous one's is refused while that stream has work in flight);
+ *   - TVBF_* environment variables (tuning and test switches that select among
+ *     routes returning the same lists, bit for bit) are looked at only in a
+ *     process started with TVBF_TUNING=1; otherwise the library calls getenv
+ *     once, for that variable, and never again.
  */
 #ifndef TVBF_H
 #define TVBF_H
@@ -43,6 +45,7 @@ extern "C" {
 #define TVBF_E_BAD_ARG (-1)   /* null pointer, negative size, k out of range ... */
 #define TVBF_E_BAD_SHAPE (-2) /* alignment / leading-dimension / workspace size  */
 #define TVBF_E_HIP (-3)       /* a HIP runtime call failed                       */
+#define TVBF_E_BUSY (-4)      /* the library-owned scratch of this GPU is in use  */
 
 #define TVBF_MAX_BLOCKS 8 /* feature blocks per row (genre, text, platform, ...) */
 #define TVBF_MAX_K 100    /* neighbours per show (bounded by the 160 KiB LDS of a CU) */
@@ -158,9 +161,14 @@ int tvbf_cosine_topk_f32(const float* Zq, int64_t nq, int64_t q_row0, const floa
  * the library runs on holds until the process ends; sizes whose workspace
  * (tvbf_topk_workspace_bytes) would be larger are rejected with TVBF_E_BAD_SHAPE.  The call
  * allocates nothing and gives the same lists as tvbf_cosine_topk_f32, bit for bit.  All calls on
- * one GPU share the array: calls that overlap on one GPU (different streams or threads) race.
- * The first call on a device looks up the array's address on that device (make it before a
- * graph capture starts).
+ * one GPU share the array.  Calls on one stream are ordered by the stream; host threads take
+ * turns (a mutex is held while a call enqueues its launches); a call on ANOTHER stream than the
+ * previous call's returns TVBF_E_BUSY while that stream still has work in flight (a caller that
+ * synchronises the first stream, or orders the two with events AND waits for the first to
+ * drain, may switch).  The first call on a device looks up the array's address on that device
+ * and must be made before a graph capture starts (TVBF_E_BUSY otherwise).  The 32 MiB are part
+ * of the library's code object: every process that loads the library holds them on every GPU
+ * it uses, whether it calls this entry point or not.
  */
 #define TVBF_STATIC_SCRATCH_BYTES (32u << 20)
 int tvbf_cosine_topk_static_f32(const float* Zq, int64_t nq, int64_t q_row0, const float* Zall, int64_t n,

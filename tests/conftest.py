@@ -8,6 +8,11 @@ from pathlib import Path
 import numpy as np
 import pytest
 
+import os
+
+# the library looks at its TVBF_* tuning / test switches only in a process started with this set
+os.environ.setdefault("TVBF_TUNING", "1")
+
 ROOT = Path(__file__).resolve().parent.parent
 for p in (str(ROOT), str(ROOT / "tests")):
     if p not in sys.path:

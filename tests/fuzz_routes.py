@@ -12,6 +12,7 @@ non-zero at the first difference (the case is named before it runs)."""
 from __future__ import annotations
 
 import os
+os.environ.setdefault("TVBF_TUNING", "1")  # the library looks at its TVBF_* switches only then
 import sys
 from pathlib import Path
 

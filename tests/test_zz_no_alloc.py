@@ -84,3 +84,38 @@ def test_static_scratch_entry_point_rejects_sizes_beyond_its_buffer(pkg, device)
     assert b"static buffer" in lib.tvbf_last_error()
     torch.cuda.synchronize()
     assert int(o[2][0]) == -7  # nothing ran
+
+
+def test_static_scratch_refuses_a_second_stream_while_the_first_is_busy(pkg, device):
+    """All calls on a GPU share the library's scratch array: a call on another stream than the
+    previous call's is refused (TVBF_E_BUSY) while that stream still has work in flight, and served
+    once it has drained -- with the same lists."""
+    import torch
+
+    from tvbingefriend_recommendation_service_amd import engine, native
+
+    lib = native.load()
+    z = engine.normalize_blocks(torch.randn((3000, 128), device=device), [0, 128], [1.0])
+    nq = n = 3000
+    k, ld = 10, z.shape[1]
+    s1, s2 = torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)
+    big = torch.randn((8192, 8192), device=device)
+    a, b = _outputs(torch, nq, k, device), _outputs(torch, nq, k, device)
+    torch.cuda.synchronize()  # the stream of the earlier calls has drained
+
+    def call(stream, outs):
+        return lib.tvbf_cosine_topk_static_f32(z.data_ptr(), nq, 0, z.data_ptr(), n, ld, ld, k, -1.0, 1,
+                                               outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), stream.cuda_stream)
+
+    with torch.cuda.stream(s1):
+        assert call(s1, a) == 0  # everything idle (the earlier calls' stream has drained): the scratch goes to s1
+        for _ in range(20):  # and s1 stays busy for tens of milliseconds
+            big = big @ big * 1e-4
+    rc = call(s2, b)
+    assert rc == -4, f"expected TVBF_E_BUSY while the first stream is busy, got {rc}"
+    assert b"another stream" in lib.tvbf_last_error()
+    s1.synchronize()
+    assert call(s2, b) == 0  # the first stream has drained: the scratch changes hands
+    torch.cuda.synchronize()
+    for got, want, name in zip(b, a, ("idx", "score", "count")):
+        assert torch.equal(got, want), name

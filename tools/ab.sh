@@ -1,4 +1,5 @@
 #!/bin/bash
+export TVBF_TUNING=1  # the library looks at its TVBF_* switches only in a process started with this set
 # A/B of library builds on one box: bash tools/ab.sh "<bench args>" lib1.so lib2.so ...  ("-" = the in-tree library)
 set -e
 ARGS=$1; shift

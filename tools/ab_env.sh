@@ -1,4 +1,5 @@
 #!/bin/bash
+export TVBF_TUNING=1  # the library looks at its TVBF_* switches only in a process started with this set
 # A/B of environment settings on one box: bash tools/ab_env.sh "<bench args>" "VAR=a" "VAR=b" ...  ("-" = no setting)
 set -e
 ARGS=$1; shift

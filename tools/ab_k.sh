@@ -1,4 +1,5 @@
 #!/bin/bash
+export TVBF_TUNING=1  # the library looks at its TVBF_* switches only in a process started with this set
 # A/B of library variants at K = 50 and K = 100 (lists in global memory): bash tools/ab_k.sh <variant> ...
 pick() { python -c "import json,sys; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', round(j['ms_per_step'],3), round(j['roofline']['frac'],4))"; }
 for v in "$@"; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+export TVBF_TUNING=1  # the library looks at its TVBF_* switches only in a process started with this set
 # A/B timing of library variants built by tools/build_variant.sh, in one process environment:
 #   bash tools/ab_variants.sh <variant> [<variant> ...]     ("main" = the shipped library)
 # prints the step time and the pipe fraction of the plain sweep, the symmetric call and the

@@ -10,6 +10,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+os.environ.setdefault("TVBF_TUNING", "1")  # the library looks at its TVBF_* switches only then
 import sys
 from pathlib import Path
 

@@ -1,4 +1,5 @@
 import os, sys, json
+os.environ.setdefault("TVBF_TUNING", "1")  # the library looks at its TVBF_* switches only then
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch
 import tvbf_amd

@@ -1,6 +1,7 @@
 """Random shapes and parameters: symmetric sweep (single catalogue and sharded job in lockstep)
 against the plain sweep, bitwise.  usage: fuzz_sym.py [CASES] [SEED] [MAX_N]"""
 import os, sys
+os.environ.setdefault("TVBF_TUNING", "1")  # the library looks at its TVBF_* switches only then
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tests"))

@@ -9,6 +9,7 @@ One plain sweep of `rows` query rows against `cols` columns of a hybrid-like mat
 when it ends; printed: the launch's span, how late workgroups start, how early they end, and the
 share of the span in which a compute unit's two workgroups are both alive."""
 import os
+os.environ.setdefault("TVBF_TUNING", "1")  # the library looks at its TVBF_* switches only then
 import sys
 from pathlib import Path
 

@@ -1,6 +1,7 @@
 """Column-side load of the symmetric sweep with one and two levels on the small tie-rich test
 matrices (usage: ring_probe.py N SHARDS)."""
 import os, sys
+os.environ.setdefault("TVBF_TUNING", "1")  # the library looks at its TVBF_* switches only then
 from pathlib import Path
 root = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(root)); sys.path.insert(0, str(root / "tests"))

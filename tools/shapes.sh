@@ -1,4 +1,5 @@
 #!/bin/bash
+export TVBF_TUNING=1  # the library looks at its TVBF_* switches only in a process started with this set
 # Kernel time / MFMA fraction of the fused kernel for the shapes quoted in the design notes.
 set -e
 for args in "" "--k 50" "--k 100" "--shows 10000 --dims 512 --data dense --steps 20" "--shows 30000 --dims 576" "--data dense"; do

@@ -14,6 +14,7 @@ ticks per k-block (the counter's own rate: see "ticks per second") and their sha
   epi     epilogue
 """
 import os
+os.environ.setdefault("TVBF_TUNING", "1")  # the library looks at its TVBF_* switches only then
 import sys
 import time
 from pathlib import Path

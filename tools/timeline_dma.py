@@ -18,6 +18,7 @@ bounds of the tile are booked as issueA, the drain of the column queue as barA, 
 it as barB and a change of row block as issueB (compare with a run of the plain timeline build);
 the three row-side counters then read: cycles inside bound refreshes, drains, refreshes."""
 import os
+os.environ.setdefault("TVBF_TUNING", "1")  # the library looks at its TVBF_* switches only then
 import sys
 import time
 from pathlib import Path

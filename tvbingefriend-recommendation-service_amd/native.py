@@ -105,7 +105,7 @@ def hipcc_command(out: Path) -> list[str]:
 
 def build(force: bool = False, verbose: bool = False) -> Path:
     """Compile csrc/*.hip for gfx950 into csrc/libtvbf.so (no GPU needed)."""
-    deps = SOURCES + [INCLUDE / "tvbf.h"]
+    deps = SOURCES + [INCLUDE / "tvbf.h"] + sorted((CSRC / "kernels").glob("*.inc"))  # tvbf_kernels.hip includes them
     if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= p.stat().st_mtime for p in deps):
         return LIB_PATH
     tmp = LIB_PATH.with_suffix(".so.tmp")
