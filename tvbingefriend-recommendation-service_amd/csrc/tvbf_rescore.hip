@@ -11,9 +11,9 @@
 // by `margin`), so that the caller can fetch more candidates for it.
 //
 //   block_norms_f64_kernel   per show and block the float64 L2 norm with sklearn's zero guard
-//   rescore_topk_kernel      one wavefront per show: its row as float64 in LDS (divided by its
-//                            norms), one gather of every candidate's stored entries, ranking by
-//                            counting, outputs and the flag
+//   rescore_topk_kernel      one workgroup per show: its row as float64 in LDS (divided by its
+//                            norms), the candidates dealt out to four wavefronts -- one gather of
+//                            a candidate's stored entries each --, ranking by counting, outputs, flag
 //   score_rows_f64_kernel    the float64 score of a few shows against ALL shows (the last resort
 //                            for a flagged row: tvbf_dense_rows_topk_f64 then selects exactly)
 // All three are bound by the gather of the candidates' rows (HBM / L2), not by arithmetic.
@@ -100,6 +100,34 @@ __device__ inline void build_image(const RSources& src, int64_t row, double* img
     wave_phase();
 }
 
+// The same by all threads of a workgroup (nt threads, barriers instead of wave fences), followed by
+// the division of every block by the show's norm of that block (sklearn's normalize: x / ||x||,
+// a norm below 10 eps counts as 1 -- preprocessing/_data.py:2010-2015).
+__device__ inline void build_scaled_image_wg(const RSources& src, const RBlocks& bd, const double* __restrict__ norms_row,
+                                             int64_t row, double* img, int d, int tid, int nt) {
+    for (int c = tid; c < d; c += nt) img[c] = 0.0;
+    __syncthreads();
+    for (int s = 0; s < src.ns; ++s) {
+        const tvbf_source& q = src.s[s];
+        if (q.kind <= TVBF_SRC_DENSE_U8) {
+            for (int c = tid; c < q.width; c += nt) img[q.z_col + c] = dense_at64(q.kind, q.data, row * q.ld + c);
+        } else {
+            const int64_t p0 = index_at64(q.indptr, q.index64, row), p1 = index_at64(q.indptr, q.index64, row + 1);
+            for (int64_t p = p0 + tid; p < p1; p += nt) {
+                const int64_t c = index_at64(q.indices, q.index64, p);
+                if (c < 0 || c >= q.width) continue;
+                atomicAdd(&img[q.z_col + c], csr_value(q, p));
+            }
+        }
+    }
+    __syncthreads();
+    for (int b = 0; b < bd.nb; ++b) {
+        const double nrm = norms_row[b];
+        for (int c = bd.off[b] + tid; c < bd.off[b + 1]; c += nt) img[c] = img[c] / nrm;
+    }
+    __syncthreads();
+}
+
 // sum over the columns [lo, hi) of img[c] * (stored value of show j at column c), wave-reduced
 __device__ inline double block_dot(const RSources& src, int lo, int hi, int64_t j, const double* img, int lane) {
     double acc = 0.0;
@@ -135,16 +163,6 @@ __device__ inline double block_dot(const RSources& src, int lo, int hi, int64_t 
         }
     }
     return wave_sum64(acc);
-}
-
-// img <- the show's row with every block divided by the show's norm of that block (sklearn's
-// normalize: x / ||x||, a norm below 10 eps counts as 1 -- preprocessing/_data.py:2010-2015)
-__device__ inline void scale_image(const RBlocks& bd, const double* __restrict__ norms_row, double* img, int lane) {
-    for (int b = 0; b < bd.nb; ++b) {
-        const double nrm = norms_row[b];
-        for (int c = bd.off[b] + lane; c < bd.off[b + 1]; c += 64) img[c] = img[c] / nrm;
-    }
-    wave_phase();
 }
 
 // The reference's score of the pair (image's show, j): per block the cosine, per group the mean of
@@ -191,7 +209,9 @@ __global__ __launch_bounds__(64) void block_norms_f64_kernel(RSources src, RBloc
     }
 }
 
-__global__ __launch_bounds__(64) void rescore_topk_kernel(
+constexpr int RESCORE_WAVES = 4;  // wavefronts per show: its candidates are dealt out to them in turn
+
+__global__ __launch_bounds__(64 * RESCORE_WAVES) void rescore_topk_kernel(
     RSources src, RBlocks bd, int d, const double* __restrict__ norms, const int32_t* __restrict__ row_ids,
     int64_t nq, int64_t q_row0, const int32_t* __restrict__ cand_idx, const float* __restrict__ cand_score,
     const int32_t* __restrict__ cand_count, int kc, int k, double min_similarity, double margin, int exclude_self,
@@ -203,17 +223,16 @@ __global__ __launch_bounds__(64) void rescore_topk_kernel(
     double* cp = sc + kc;                        // kc x 3 group cosines
     int32_t* col = reinterpret_cast<int32_t*>(cp + 3 * kc);  // kc columns (-1: not a neighbour)
     __shared__ double v_k;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t r = blockIdx.x;
-    if (r >= nq) return;
+    if (r >= nq) return;  // the whole workgroup
     const int64_t show = row_ids ? (int64_t)row_ids[r] : q_row0 + r;
     const int64_t orow = row_ids ? show - out_row0 : r;
-    build_image(src, show, img, d, lane);
-    scale_image(bd, norms + show * bd.nb, img, lane);
+    build_scaled_image_wg(src, bd, norms + show * bd.nb, show, img, d, tid, 64 * RESCORE_WAVES);
 
     int cnt = cand_count[r];
     if (cnt > kc) cnt = kc;
-    for (int s = 0; s < cnt; ++s) {
+    for (int s = wave; s < cnt; s += RESCORE_WAVES) {
         const int64_t j = cand_idx[r * kc + s];
         if (j < 0 || (exclude_self && j == show)) {
             if (lane == 0) col[s] = -1, sc[s] = 0.0;
@@ -228,8 +247,9 @@ __global__ __launch_bounds__(64) void rescore_topk_kernel(
             cp[3 * s] = comp[0], cp[3 * s + 1] = comp[1], cp[3 * s + 2] = comp[2];
         }
     }
-    if (lane == 0) v_k = -INFINITY;
-    wave_phase();
+    if (tid == 0) v_k = -INFINITY;
+    __syncthreads();
+    if (wave) return;  // ranking and output: one wavefront
 
     // rank by counting: (score descending, column ascending) among the kept candidates
     int n_pass = 0;
@@ -289,11 +309,7 @@ __global__ __launch_bounds__(256) void score_rows_f64_kernel(RSources src, RBloc
     extern __shared__ double img_lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t show = row_ids[blockIdx.y];
-    if (wave == 0) {
-        build_image(src, show, img_lds, d, lane);
-        scale_image(bd, norms + show * bd.nb, img_lds, lane);
-    }
-    __syncthreads();
+    build_scaled_image_wg(src, bd, norms + show * bd.nb, show, img_lds, d, threadIdx.x, 256);
     const int64_t j0 = (int64_t)blockIdx.x * cols_per_wg;
     int64_t j1 = j0 + cols_per_wg;
     if (j1 > n) j1 = n;
@@ -398,9 +414,9 @@ int tvbf_rescore_topk_f64(const tvbf_source* sources, int ns, int64_t n, int64_t
     if (nq == 0) return TVBF_OK;
     const size_t lds = ((size_t)d + 4 * (size_t)kc) * sizeof(double) + (size_t)kc * sizeof(int32_t);
     if (int rc = allow_lds(rescore_topk_kernel, lds)) return rc;
-    hipLaunchKernelGGL(rescore_topk_kernel, dim3((unsigned)nq), dim3(64), lds, (hipStream_t)stream, src, bd, (int)d,
-                       norms, row_ids, nq, q_row0, cand_idx, cand_score, cand_count, kc, k, min_similarity, margin,
-                       exclude_self, out_idx, out_score, out_comp, out_count, out_row0, flagged);
+    hipLaunchKernelGGL(rescore_topk_kernel, dim3((unsigned)nq), dim3(64 * RESCORE_WAVES), lds, (hipStream_t)stream, src,
+                       bd, (int)d, norms, row_ids, nq, q_row0, cand_idx, cand_score, cand_count, kc, k, min_similarity,
+                       margin, exclude_self, out_idx, out_score, out_comp, out_count, out_row0, flagged);
     HIP_TRY(hipGetLastError());
     return TVBF_OK;
 }
