@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--min-similarity", type=float, default=None)
     ap.add_argument("--seed", type=int, default=30001)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32-compare", action="store_true",
+                    help="skip the few fp32-only steps timed after the main region (profiling runs: one kind of step per run)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-to-host measurement (one GPU only)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo is a rehearsal mode: the shards are exchanged through host memory")
@@ -494,7 +496,7 @@ def main():
 
     # the fp32-only step (lists of the fp32 scores + K5), timed the same way on a few steps, beside the exact one
     fp32_step = None
-    if exact:
+    if exact and not args.no_fp32_compare:
         n_cmp = max(1, min(args.steps, 8))
         if world > 1 and symmetric and kc != args.k and not sharding.symmetric_route_fits(world, args.k, ld):
             n_cmp = 0

@@ -5,7 +5,7 @@ set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc_${1:-r01}
 shift || true
-ARGS="${*:---steps 1 --warmup 0 --no-cpu-baseline}"
+ARGS="${*:---steps 1 --warmup 0 --no-cpu-baseline --no-fp32-compare}"
 mkdir -p $OUT
 pass() { name=$1; shift
   timeout -s KILL 240 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 bench.py $ARGS > $OUT/$name.log 2>&1 || { echo "pass $name failed"; tail -5 $OUT/$name.log; return 1; }

@@ -21,7 +21,7 @@ import argparse
 ap = argparse.ArgumentParser()
 ap.add_argument("tag")
 ap.add_argument("mode", choices=["plain", "symmetric", "matrix"])
-ap.add_argument("--round", default="r02")
+ap.add_argument("--round", default="r03")
 ap.add_argument("--n", type=int, default=100_000)
 ap.add_argument("--d", type=int, default=1024)
 ap.add_argument("--k", type=int, default=20)
