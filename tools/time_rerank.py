@@ -69,7 +69,16 @@ def main():
         stats.update(engine.exact_topk(z, src, offsets, groups, weights, k, ms, norms=norms).stats)
 
     t_exact = timed(torch, whole, reps=3)
-    for rk in (48, 64, 100):
+    for kc_try in (24, 26, 28, 30):
+        st3 = {}
+
+        def run():
+            c = engine.catalogue_topk(z, kc_try, ms - engine.THRESHOLD_BAND)
+            st3.update(engine.exact_topk(z, src, offsets, groups, weights, k, ms, norms=norms, cand=c).stats)
+
+        t = timed(torch, run, reps=3)
+        print(f"  sweep for {kc_try} candidates + re-rank: {t:.2f} ms, stages {st3}")
+    for rk in (max(48, k), 100):
         st2 = {}
         t = timed(torch, lambda: st2.update(engine.exact_topk(z, src, offsets, groups, weights, k, ms, norms=norms, resweep_k=rk).stats), reps=3)
         print(f"  second stage with {rk} candidates: {t:.2f} ms, stages {st2}")

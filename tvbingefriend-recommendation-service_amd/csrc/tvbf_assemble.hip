@@ -183,6 +183,11 @@ extern "C" int tvbf_assemble_normalize_f32(const tvbf_source* sources, int ns, i
         src.s[s] = q;
     }
     if (n == 0) return TVBF_OK;
+    // one packed fp32 matrix that covers all columns is K1's own input: its kernel keeps the row in
+    // registers (no LDS round trip) and writes the same bits
+    if (ns == 1 && src.s[0].kind == TVBF_SRC_DENSE_F32 && src.s[0].z_col == 0 && src.s[0].width == d)
+        return tvbf_normalize_blocks_f32(static_cast<const float*>(src.s[0].data), n, d, src.s[0].ld, block_offsets,
+                                         block_scales, nb, Z, ldz, stream);
     const size_t row_bytes = (size_t)ldz * sizeof(float);
     const size_t lds_max = 160 * 1024;
     if (row_bytes > lds_max) return tvbf_fail(TVBF_E_BAD_SHAPE, "ldz too large for one LDS row (max %zu)", lds_max / 4);

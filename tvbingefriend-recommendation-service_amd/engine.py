@@ -447,10 +447,20 @@ def candidate_count(k: int) -> int:
     return k + 8 if k + 8 <= 30 else max(k, min(k + 16, native.TVBF_MAX_K))
 
 
+def threshold_keys(t: torch.Tensor) -> torch.Tensor:
+    """The 64-bit bound keys (int64 bit patterns) of fp32 thresholds ``t``: the order-preserving
+    integer image of the score in the high word, low word 0 -- every (score, column) key of a score
+    >= t is larger.  What a :class:`TopkSession` holds in ``bounds()``."""
+    u = t.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    flip = torch.where((u >> 31) != 0, torch.full_like(u, 0xFFFFFFFF), torch.full_like(u, 0x80000000))
+    return (u ^ flip) << 32
+
+
 def resweep_candidate_count(k: int) -> int:
     """Candidates per show of the second stage (rows whose first list ended inside a group of tied
-    scores): 2 k + 16, at least 48, at most the sweeps' limit."""
-    return max(int(k), min(native.TVBF_MAX_K, max(48, 2 * int(k) + 16)))
+    scores): the sweeps' limit -- the stage starts from a per-row bound, so only the shows inside
+    the band of scores that can still matter reach the lists."""
+    return max(int(k), native.TVBF_MAX_K)
 
 
 def block_norms(sources, n: int, offsets, *, check_finite: bool = True) -> torch.Tensor:
@@ -593,8 +603,18 @@ def exact_topk(z: torch.Tensor, sources, offsets, groups, group_weights, k: int,
             out.stats["resweep"] = nf
             if resweep is None:
                 def resweep(ids, kk):
-                    zq = z.index_select(0, ids.long()) if z_q is None else z_q.index_select(0, ids.long() - q_row0)
-                    return cosine_topk(z, kk, min_similarity - band, z_q=zq, n=n, exclude_self=False)
+                    # A show of the true list has a float64 score of at least max(min_similarity, c_K - margin),
+                    # c_K the K-th best fp32 score found (K shows score at least c_K - margin in float64), hence an
+                    # fp32 score of at least t = max(min_similarity - band, c_K - 2 margin): the sweep starts with
+                    # that as the row's bound, so its lists fill with the few shows of that band only.
+                    local = ids.long() - q_row0
+                    zq = z.index_select(0, ids.long()) if z_q is None else z_q.index_select(0, local)
+                    floor = torch.full((ids.numel(),), min_similarity - band, dtype=torch.float32, device=dev)
+                    t = torch.maximum(floor, cand.score.index_select(0, local)[:, k - 1] - 2.0 * float(margin))
+                    ses = TopkSession(zq, ids.numel(), 0, kk, min_similarity - band, exclude_self=False)
+                    ses.bounds().copy_(threshold_keys(t))
+                    ses.accumulate((z, n, 0))
+                    return ses.finish()
             cand2 = resweep(rows, kc2)
             flagged2 = torch.zeros(1 + nf, dtype=torch.int32, device=dev)
             rescore_topk(sources, n, offsets, groups, group_weights, norms, cand2, k, min_similarity, out,
