@@ -553,6 +553,51 @@ def score_rows(sources, n: int, offsets, groups, group_weights, norms: torch.Ten
 SCAN_BYTES = 1 << 30  # float64 score rows held at a time by the last-resort scan
 
 
+BAND_ROWS_MAX = 1024   # up to this many uncertified rows the second stage takes the dense-strip route (a rank's 194 rows of 12,500: 1.7 against 4.1 ms; 1,528 rows of 100,000: 81.6 against 80.5 ms per call)
+BAND_LIST_MAX = 1024   # candidates per show the re-rank kernel takes
+
+
+def _band_stage(z, z_q, sources, n, offsets, groups, group_weights, norms, cand, rows, k, min_similarity, out, q_row0,
+                margin, band) -> torch.Tensor:
+    """Second stage of :func:`exact_topk` for the shows ``rows`` (int32, sorted): their fp32 scores
+    against all shows as a dense strip (the tile engine's numbers), and as candidates EVERY show whose
+    fp32 score reaches t = max(min_similarity - band, c_K - 2 margin), c_K the K-th best fp32 score of
+    the first stage.  A show of the true list has a float64 score of at least
+    max(min_similarity, c_K - margin) (K shows are known to score c_K - margin or more), hence an
+    fp32 score of at least t: the candidate list is complete, whatever its length, and the re-rank
+    of it is final.  Returns the shows with BAND_LIST_MAX or more such candidates (groups of a
+    thousand tied shows): they go on to the scan."""
+    dev = z.device
+    left = []
+    step = max(1, min(int(rows.numel()), SCAN_BYTES // (4 * n)))
+    for b0 in range(0, int(rows.numel()), step):
+        ids = rows[b0:b0 + step].contiguous()
+        local = ids.long() - q_row0
+        zq = z.index_select(0, ids.long()) if z_q is None else z_q.index_select(0, local)
+        floor = torch.full((ids.numel(),), min_similarity - band, dtype=torch.float32, device=dev)
+        t = torch.maximum(floor, cand.score.index_select(0, local)[:, k - 1] - 2.0 * float(margin))
+        h = gram(z, z_q=zq, n=n)
+        mask = h >= t[:, None]
+        cnt = mask.sum(dim=1)
+        kc = int(min(BAND_LIST_MAX, max(int(cnt.max().item()) + 1, k)))
+        pair = mask.nonzero()  # (pairs, 2), row-major: a row's columns ascending
+        r_, c_ = pair[:, 0], pair[:, 1]
+        pos = torch.arange(pair.shape[0], device=dev) - (torch.cumsum(cnt, 0) - cnt)[r_]
+        keep = pos < kc
+        idx = torch.full((ids.numel(), kc), -1, dtype=torch.int32, device=dev)
+        score = torch.zeros((ids.numel(), kc), dtype=torch.float32, device=dev)
+        idx[r_[keep], pos[keep]] = c_[keep].to(torch.int32)
+        score[r_[keep], pos[keep]] = h[r_[keep], c_[keep]]
+        over = cnt >= kc  # more shows in the band than a list takes: not decided here
+        count = torch.where(over, torch.zeros_like(cnt), cnt).to(torch.int32)
+        rescore_topk(sources, n, offsets, groups, group_weights, norms, TopK(idx, score, count), k, min_similarity, out,
+                     q_row0=q_row0, row_ids=ids, margin=margin)
+        if bool(over.any()):
+            left.append(ids[over])
+        del h, mask
+    return torch.cat(left).contiguous() if left else torch.empty(0, dtype=torch.int32, device=dev)
+
+
 def exact_topk(z: torch.Tensor, sources, offsets, groups, group_weights, k: int, min_similarity: float, *,
                n: int | None = None, q_row0: int = 0, nq: int | None = None, cand: TopK | None = None,
                z_q: torch.Tensor | None = None, resweep=None, resweep_k: int | None = None,
@@ -599,7 +644,16 @@ def exact_topk(z: torch.Tensor, sources, offsets, groups, group_weights, k: int,
             return out
         rows = flagged[1:1 + nf].sort().values.contiguous()
         kc2 = resweep_candidate_count(k) if resweep_k is None else int(resweep_k)
-        if kc2 > kc:  # stage 2: a longer list for just these rows
+        if resweep is None and resweep_k is None and nf <= BAND_ROWS_MAX:
+            # stage 2 for a few rows: all their fp32 scores as a dense strip, every show inside the band
+            # of scores that can still matter as a candidate -- complete by construction
+            out.stats["resweep"] = nf
+            rows = _band_stage(z, z_q, sources, n, offsets, groups, group_weights, norms, cand, rows, k, min_similarity,
+                               out, q_row0, margin, band)
+            nf = int(rows.numel())
+            if nf == 0:
+                return out
+        elif kc2 > kc:  # stage 2: a longer list for just these rows
             out.stats["resweep"] = nf
             if resweep is None:
                 def resweep(ids, kk):
@@ -637,9 +691,10 @@ def exact_topk(z: torch.Tensor, sources, offsets, groups, group_weights, k: int,
 
 
 def gram(z_all: torch.Tensor, *, col0: int = 0, width: int | None = None, q_row0: int = 0,
-         nq: int | None = None, n: int | None = None) -> torch.Tensor:
+         nq: int | None = None, n: int | None = None, z_q: torch.Tensor | None = None) -> torch.Tensor:
     """Dense (nq, n) fp32 matrix z[q rows, cols] @ z[:, cols].T over the column
-    range [col0, col0 + width) of z (default: all columns).  For small n only."""
+    range [col0, col0 + width) of z (default: all columns); ``z_q`` gives the query rows as a
+    separate (nq, ld) tensor.  For small nq x n only."""
     _require_cuda(z_all, "z_all")
     if z_all.dim() != 2 or not z_all.is_contiguous():
         raise ValueError("z_all must be a contiguous 2-D tensor")
@@ -649,13 +704,19 @@ def gram(z_all: torch.Tensor, *, col0: int = 0, width: int | None = None, q_row0
     width = ld - col0 if width is None else int(width)
     if col0 % 4 or width % 4 or col0 < 0 or col0 + width > ld:
         raise ValueError("column ranges must be multiples of 4 floats inside the row")
-    if q_row0 < 0 or q_row0 + nq > z_all.shape[0] or not 1 <= n <= z_all.shape[0]:
+    if z_q is not None:
+        _require_cuda(z_q, "z_q")
+        if z_q.dim() != 2 or not z_q.is_contiguous() or z_q.shape[1] != ld:
+            raise ValueError("z_q must be contiguous with the same row length as z_all")
+        nq, q_row0 = z_q.shape[0], 0
+    if q_row0 < 0 or (z_q is None and q_row0 + nq > z_all.shape[0]) or not 1 <= n <= z_all.shape[0]:
         raise ValueError("rows outside z_all")
     out = torch.empty((nq, n), dtype=torch.float32, device=z_all.device)
     lib = native.load()
     base = z_all.data_ptr() + col0 * 4
+    q_base = base + q_row0 * ld * 4 if z_q is None else z_q.data_ptr() + col0 * 4
     with torch.cuda.device(z_all.device):
-        rc = lib.tvbf_gram_f32(base + q_row0 * ld * 4, nq, base, n, width, ld, out.data_ptr(), n, _stream_ptr())
+        rc = lib.tvbf_gram_f32(q_base, nq, base, n, width, ld, out.data_ptr(), n, _stream_ptr())
     native.check(rc, "tvbf_gram_f32")
     return out
 
