@@ -95,6 +95,24 @@ def make_shard(args, shard, dev):
     return x, [0, 32, 32 + dt, d], [0.4, 0.5, 0.1]
 
 
+def stored_sources(engine, x, offsets):
+    """The packed hybrid rows as the five arrays the reference stores (scripts/compute_features.py:115-129:
+    genre int64, TF-IDF CSR float64, platform float64, type bool, language float64) on the device -- what the
+    drop-in uploads from the feature files -- as sources of K1's assembly and of the float64 re-rank."""
+    import torch
+
+    g0, t0, m0 = offsets[0], offsets[1], offsets[2]
+    dt = m0 - t0
+    csr = x[:, t0:m0].to_sparse_csr()
+    meta = x[:, m0:]
+    return [engine.DenseSource(x[:, g0:t0].to(torch.int64), g0),
+            engine.CsrSource(csr.crow_indices().contiguous(), csr.col_indices().contiguous(),
+                             csr.values().to(torch.float64), dt, t0),
+            engine.DenseSource(meta[:, :21].to(torch.float64), m0),
+            engine.DenseSource(meta[:, 21:26] != 0, m0 + 21),
+            engine.DenseSource(meta[:, 26:].to(torch.float64), m0 + 26)]
+
+
 def cpu_baseline(x_host, offsets, weights, k, min_similarity, budget_s):
     """The oracle (a NumPy port of the reference path) timed on the host cores on a bounded
     sample: query rows in chunks of 512 against all n columns, float64 like the reference,
@@ -282,21 +300,25 @@ def main():
     nq = shard.rows
     groups = [0, 1, 2][: len(weights)]
     gw = (list(weights) + [0.0, 0.0])[:3]
-    if exact:
-        # the stored features of ALL shows on every rank (what every rank of the reference's pipeline
-        # loads from the feature files): gathered once, before the timed region
-        if world == 1:
-            x_all = x
-        elif args.backend == "nccl":
-            x_all = torch.empty((shard.padded_total, args.d), dtype=torch.float32, device=dev)
-            dist.all_gather_into_tensor(x_all, x)
-        else:
-            parts = [torch.empty((shard.per_rank, args.d), dtype=torch.float32) for _ in range(world)]
-            dist.all_gather(parts, x.cpu())
-            x_all = torch.cat(parts, dim=0).to(dev)
+    # The stored features of ALL shows on every rank (what every rank of the reference's pipeline loads
+    # from the feature files; the float64 re-rank reads the candidates' stored rows): every rank
+    # generates all shards itself, before the timed region.  Hybrid rows are kept in the reference's
+    # stored form (int64 genres, CSR float64 text, float64 / bool one-hots), dense rows as one packed
+    # fp32 matrix.
+    if world == 1:
+        x_all = x
+    else:
+        x_all = torch.cat([make_shard(args, sharding.shard_bounds(args.n, world, r), dev)[0] for r in range(world)])
+    if args.data == "hybrid":
+        src_all = stored_sources(engine, x_all[: args.n], offsets)
+    else:
         src_all = [engine.DenseSource(x_all[: args.n], 0)]
-        src_shard = [engine.DenseSource(x, 0)]
-        out64 = None
+    src_shard = engine.slice_sources(src_all, shard.row0, nq)
+    x_host = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        x_host = x[:nq].cpu().numpy()
+    del x, x_all  # only the stored form stays on the device (for dense rows it is the packed matrix itself)
+    z_shard.zero_()  # padding rows of the last shard stay zero
 
     def new_out(kk):
         return engine.TopK(torch.empty((nq, kk), dtype=torch.int32, device=dev),
@@ -395,10 +417,8 @@ def main():
         ms_sweep = sweep_min if path_exact else min_sim
         res = out if kk == kc else out_k
         mark("start")
-        if path_exact:  # the drop-in's K1: assembled from the stored arrays (here one dense fp32 source)
-            engine.assemble_normalize(src_shard, shard.per_rank, offsets, scales, out=z_shard)
-        else:
-            engine.normalize_blocks(x, offsets, scales, out=z_shard)
+        if nq:  # the drop-in's K1: this rank's rows of Z assembled from the stored arrays
+            engine.assemble_normalize(src_shard, nq, offsets, scales, out=z_shard[:nq])
         mark("k1")
         work = start_gather()
         if symmetric and world == 1:
@@ -595,9 +615,6 @@ def main():
                              "the HIP-event time, a physical pipe fraction; effective_vs_2N2D credits 2*D flops "
                              "for every ordered pair, computed or not (the work the path is specified by)"},
     }
-    x_host = None  # --no-cpu-baseline skips both host-side legs (profiling runs)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        x_host = x[:nq].cpu().numpy()
     if x_host is not None and not args.no_end_to_end and len(weights) == 3:
         del workspace  # the measurement allocates its own
         line["end_to_end"] = end_to_end(x_host, offsets, weights, args.k, min_sim, dev)

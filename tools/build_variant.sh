@@ -8,5 +8,5 @@ mkdir -p build
 SRC=tvbingefriend-recommendation-service_amd/csrc
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -Iinclude \
   -Xclang -target-feature -Xclang -packed-fp32-ops "$@" -o build/libtvbf_$NAME.so \
-  $SRC/tvbf_kernels.hip $SRC/tvbf_stats.hip $SRC/tvbf_assemble.hip 2>&1 | grep -v "packed-fp32-ops" || true
+  $SRC/tvbf_kernels.hip $SRC/tvbf_stats.hip $SRC/tvbf_assemble.hip $SRC/tvbf_rescore.hip 2>&1 | grep -v "packed-fp32-ops" || true
 ls -la build/libtvbf_$NAME.so
