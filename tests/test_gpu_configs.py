@@ -296,6 +296,52 @@ def test_config3_float64_rerank_every_row(pkg, device, k, ms, kind):
           f"float64 ties), max score error {max_err:.2e}, stages {top.stats}")
 
 
+def test_config5_one_rank_of_eight_float64_rerank(pkg, device):
+    """BASELINE config #5 (N = 1,000,000 x 2048 hybrid-like, K = 50, min 0.1, 8 ranks), one rank's share
+    through the float64 re-rank: the rank's 125,000 rows swept against all columns for 66 candidates
+    (plain sharded route), re-ranked from the stored rows of all shows, later stages for the rows that
+    cannot be certified -- against float64 scores of the rank's 1.25e11 pairs computed by torch: every
+    rank that is not an exact float64 tie holds the same show, scores to 1e-12, counts exact."""
+    import torch
+
+    from parity import REFINED_GAP, REFINED_TOL
+    from tvbingefriend_recommendation_service_amd import engine, sharding
+
+    if torch.cuda.get_device_properties(device).total_memory < 200 * 2**30:
+        pytest.skip("needs about 60 GB of device memory")
+    n, d, k, ms, world, rank = 1_000_000, 2048, 50, 0.1, 8, 5
+    offsets, weights = [0, 32, d - 32, d], [0.4, 0.5, 0.1]
+    scales = [float(np.sqrt(w)) for w in weights]
+    me = sharding.shard_bounds(n, world, rank)
+    x_all = torch.empty((n, d), device=device)
+    z_all = torch.empty((n, d), device=device)
+    for c0 in range(0, n, CHUNK):
+        x_all[c0:c0 + CHUNK] = _hybrid_chunk(torch, device, CHUNK, d, 50001 + c0 // CHUNK)
+        engine.normalize_blocks(x_all[c0:c0 + CHUNK], offsets, scales, out=z_all[c0:c0 + CHUNK])
+    kc = engine.candidate_count(k)
+    own, after, before = sharding.column_pieces(me)
+    zq = z_all[me.row0:me.row0 + me.rows]
+    ses = engine.TopkSession(zq, me.rows, me.row0, kc, ms - engine.THRESHOLD_BAND)
+    ses.accumulate((zq, own[1], own[0]))
+    ses.accumulate((z_all[after[0]:], after[1], after[0]), (z_all, before[1], before[0]))
+    cand = ses.finish()
+    del ses
+    top = engine.exact_topk(z_all, [engine.DenseSource(x_all, 0)], offsets, [0, 1, 2], weights, k, ms, n=n,
+                            q_row0=me.row0, nq=me.rows, cand=cand)
+    torch.cuda.synchronize()
+    del z_all, cand
+    z64_all = torch.empty((n, d), dtype=torch.float64, device=device)
+    for c0 in range(0, n, CHUNK):
+        z64_all[c0:c0 + CHUNK] = _z_float64(torch, x_all[c0:c0 + CHUNK], offsets, weights)
+    del x_all
+    ranks, exact, max_err = _compare_with_float64_rows(torch, device, z64_all[me.row0:me.row0 + me.rows], z64_all, me.row0,
+                                                       top, k, ms, 250, tol=REFINED_TOL, gap=REFINED_GAP,
+                                                       count_band=REFINED_TOL)
+    assert ranks > 0.99 * me.rows * k
+    print(f"config 5, rank {rank} of {world}, float64 re-rank: {ranks} ranks, {exact} compared by index "
+          f"({ranks - exact} in exact float64 ties), max score error {max_err:.2e}, stages {top.stats}")
+
+
 def test_config4_eight_ranks_at_100k_x_1024(pkg, device):
     """BASELINE config #4 at full size: the eight ranks of the row-sharded job, driven in lockstep on
     one GPU (collectives replaced by indexing) -- symmetric sharded route with the own blocks through
