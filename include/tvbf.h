@@ -345,6 +345,24 @@ int tvbf_gram_f32(const float* Zq, int64_t nq, const float* Zall, int64_t n, int
                   float* out, int64_t ldo, void* stream);
 
 /*
+ * Every show inside a band of scores, for a few query rows: out_idx[i, 0 .. min(count, cap)) are the
+ * columns j with score(i, j) = sum_c Zq[i, c] * Zall[j, c] >= thresholds[i] (the fp32 number of
+ * tvbf_cosine_topk_f32 and tvbf_gram_f32), in no particular order, out_score their scores;
+ * out_count[i] counts ALL such columns and may exceed cap (the rest was dropped).  One score tile per
+ * workgroup and no lists: any number of rows fills the GPU.  The second stage of the float64 re-rank
+ * (tvbf_rescore_topk_f64): a show of the reference's list (scripts/populate_database.py:195-218) has
+ * an fp32 score of at least max(min_similarity, K-th best fp32 score) minus twice the fp32 error, so
+ * the columns above that threshold are a complete candidate list.  No counterpart in the reference.
+ *
+ *   Zq          device, nq x d fp32, row stride ld (any rows, e.g. gathered ones); Zall n x d likewise
+ *   thresholds  device, nq fp32
+ *   out_idx     device, nq x cap int32; out_score nq x cap fp32; out_count nq uint32 (zeroed by the call)
+ */
+int tvbf_band_candidates_f32(const float* Zq, int64_t nq, const float* Zall, int64_t n, int64_t d, int64_t ld,
+                             const float* thresholds, int cap, int32_t* out_idx, float* out_score,
+                             uint32_t* out_count, void* stream);
+
+/*
  * K5 -- per-block cosine of every kept pair.
  * Replaces the component-score look-ups of scripts/populate_database.py:214-216
  * and services/content_based_service.py:227-229.

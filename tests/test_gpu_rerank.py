@@ -134,15 +134,15 @@ def test_rerank_stages_on_tie_heavy_catalogue(pkg, device):
 
     h, _ = _oracle_hybrid(feats, (0.4, 0.5, 0.1), "populate")
     results = []
-    # the second stage as a dense strip (every show of the band a candidate: the 300-group fits a list),
-    # the same with lists of 64 (the large groups go on to the scan), and as a sweep with longer lists
-    for name, patch in (("strip", {}), ("strip, short lists", {"BAND_LIST_MAX": 64}), ("sweep", {"BAND_ROWS_MAX": 0})):
+    # the second stage with lists of 1024 (every show of the band a candidate: the 300-group fits a list)
+    # and with lists of 64 (the large groups go on to the scan of all shows)
+    for name, patch in (("band", {}), ("band, short lists", {"BAND_LIST_MAX": 64})):
         with pytest.MonkeyPatch.context() as mp:
             for attr, value in patch.items():
                 mp.setattr(engine, attr, value)
             res, st = _exact(pkg, device, feats, (0.4, 0.5, 0.1), "populate", k, ms)
         assert st["resweep"] >= 300, (name, st)
-        assert (st["scan"] == 0) if name == "strip" else (st["scan"] >= 200), (name, st)
+        assert (st["scan"] == 0) if name == "band" else (st["scan"] >= 200), (name, st)
         stats = {}
         check_topk_against_scores(h, 0, k, ms, res.idx, res.score, res.count, tol=REFINED_TOL, gap=REFINED_GAP,
                                   what=f"tie-heavy ({name})", stats=stats, f64=True, check_tie_order=False)
@@ -152,7 +152,7 @@ def test_rerank_stages_on_tie_heavy_catalogue(pkg, device):
             assert res.idx[i].tolist() == want and np.all(np.abs(res.score[i] - 1.0) <= 1e-15)
         print(f"tie-heavy ({name}): {stats}, stages {st}")
         results.append(res)
-    for other in results[1:]:  # all three routes: the same lists, scores and component scores, bit for bit
+    for other in results[1:]:  # both ways: the same lists, scores and component scores, bit for bit
         for f in ("idx", "score", "count", "comp"):
             assert np.array_equal(getattr(results[0], f), getattr(other, f)), f
 

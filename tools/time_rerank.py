@@ -78,17 +78,13 @@ def main():
 
         t = timed(torch, run, reps=3)
         print(f"  sweep for {kc_try} candidates + re-rank: {t:.2f} ms, stages {st3}")
-    share = n // 8  # one rank's rows of an 8-rank job: the re-rank stages after the sweep, strip against sweep route
+    share = n // 8  # one rank's rows of an 8-rank job: the re-rank stages after the sweep
     cand_share = engine.cosine_topk(z, kc, ms - engine.THRESHOLD_BAND, q_row0=0, nq=share)
-    for name, rows_max in (("strip", engine.BAND_ROWS_MAX), ("sweep", 0)):
-        keep = engine.BAND_ROWS_MAX
-        engine.BAND_ROWS_MAX = rows_max
-        st4 = {}
-        t = timed(torch, lambda: st4.update(engine.exact_topk(z, src, offsets, groups, weights, k, ms, norms=norms, q_row0=0,
-                                                                nq=share, cand=cand_share).stats), reps=5)
-        engine.BAND_ROWS_MAX = keep
-        print(f"  re-rank of {share} rows (one rank of eight), second stage as {name}: {t:.2f} ms, stages {st4}")
-    for rk in (max(48, k), 100):
+    st4 = {}
+    t = timed(torch, lambda: st4.update(engine.exact_topk(z, src, offsets, groups, weights, k, ms, norms=norms, q_row0=0,
+                                                            nq=share, cand=cand_share).stats), reps=5)
+    print(f"  re-rank of {share} rows (one rank of eight): {t:.2f} ms, stages {st4}")
+    for rk in (100,):  # second stage as a plain sweep of the flagged rows for 100 candidates instead of the band kernel
         st2 = {}
         t = timed(torch, lambda: st2.update(engine.exact_topk(z, src, offsets, groups, weights, k, ms, norms=norms, resweep_k=rk).stats), reps=3)
         print(f"  second stage with {rk} candidates: {t:.2f} ms, stages {st2}")

@@ -553,49 +553,58 @@ def score_rows(sources, n: int, offsets, groups, group_weights, norms: torch.Ten
 SCAN_BYTES = 1 << 30  # float64 score rows held at a time by the last-resort scan
 
 
-BAND_ROWS_MAX = 1024   # up to this many uncertified rows the second stage takes the dense-strip route (a rank's 194 rows of 12,500: 1.7 against 4.1 ms; 1,528 rows of 100,000: 81.6 against 80.5 ms per call)
 BAND_LIST_MAX = 1024   # candidates per show the re-rank kernel takes
+BAND_BYTES = 512 << 20  # candidate buffers (column + score) of one second-stage launch
+
+
+def band_candidates(z: torch.Tensor, z_q: torch.Tensor, thresholds: torch.Tensor, cap: int, *, n: int | None = None):
+    """Every show whose fp32 score against a query row reaches that ROW'S threshold: (idx (nq, cap)
+    int32, score (nq, cap) fp32, count (nq,) int32 -- all such shows, may exceed cap).  ``z_q`` holds
+    the query rows (any rows, e.g. gathered ones), ``z`` all n shows; one launch, no lists."""
+    _require_cuda(z, "z")
+    _require_cuda(z_q, "z_q")
+    _require_cuda(thresholds, "thresholds")
+    if z.dim() != 2 or not z.is_contiguous() or z_q.dim() != 2 or not z_q.is_contiguous() or z_q.shape[1] != z.shape[1]:
+        raise ValueError("z and z_q must be contiguous 2-D tensors of one row length")
+    nq = z_q.shape[0]
+    n = z.shape[0] if n is None else int(n)
+    if thresholds.numel() != nq or not thresholds.is_contiguous():
+        raise ValueError("one contiguous fp32 threshold per query row")
+    idx = torch.empty((nq, cap), dtype=torch.int32, device=z.device)
+    score = torch.empty((nq, cap), dtype=torch.float32, device=z.device)
+    count = torch.empty((nq,), dtype=torch.int32, device=z.device)
+    with torch.cuda.device(z.device):
+        rc = native.load().tvbf_band_candidates_f32(z_q.data_ptr(), nq, z.data_ptr(), n, z.shape[1], z.shape[1],
+                                                    thresholds.data_ptr(), int(cap), idx.data_ptr(), score.data_ptr(),
+                                                    count.data_ptr(), _stream_ptr())
+    native.check(rc, "tvbf_band_candidates_f32")
+    return idx, score, count
 
 
 def _band_stage(z, z_q, sources, n, offsets, groups, group_weights, norms, cand, rows, k, min_similarity, out, q_row0,
                 margin, band) -> torch.Tensor:
-    """Second stage of :func:`exact_topk` for the shows ``rows`` (int32, sorted): their fp32 scores
-    against all shows as a dense strip (the tile engine's numbers), and as candidates EVERY show whose
-    fp32 score reaches t = max(min_similarity - band, c_K - 2 margin), c_K the K-th best fp32 score of
-    the first stage.  A show of the true list has a float64 score of at least
-    max(min_similarity, c_K - margin) (K shows are known to score c_K - margin or more), hence an
+    """Second stage of :func:`exact_topk` for the shows ``rows`` (int32, sorted): as candidates EVERY
+    show whose fp32 score reaches t = max(min_similarity - band, c_K - 2 margin), c_K the K-th best
+    fp32 score of the first stage (tvbf_band_candidates_f32: the tile engine's numbers, one score tile
+    per workgroup, whatever the number of rows).  A show of the true list has a float64 score of at
+    least max(min_similarity, c_K - margin) (K shows are known to score c_K - margin or more), hence an
     fp32 score of at least t: the candidate list is complete, whatever its length, and the re-rank
-    of it is final.  Returns the shows with BAND_LIST_MAX or more such candidates (groups of a
+    of it is final.  Returns the shows with more such candidates than a list takes (groups of a
     thousand tied shows): they go on to the scan."""
     dev = z.device
     left = []
-    step = max(1, min(int(rows.numel()), SCAN_BYTES // (4 * n)))
-    for b0 in range(0, int(rows.numel()), step):
-        ids = rows[b0:b0 + step].contiguous()
-        local = ids.long() - q_row0
-        zq = z.index_select(0, ids.long()) if z_q is None else z_q.index_select(0, local)
-        floor = torch.full((ids.numel(),), min_similarity - band, dtype=torch.float32, device=dev)
-        t = torch.maximum(floor, cand.score.index_select(0, local)[:, k - 1] - 2.0 * float(margin))
-        h = gram(z, z_q=zq, n=n)
-        mask = h >= t[:, None]
-        cnt = mask.sum(dim=1)
-        kc = int(min(BAND_LIST_MAX, max(int(cnt.max().item()) + 1, k)))
-        pair = mask.nonzero()  # (pairs, 2), row-major: a row's columns ascending
-        r_, c_ = pair[:, 0], pair[:, 1]
-        pos = torch.arange(pair.shape[0], device=dev) - (torch.cumsum(cnt, 0) - cnt)[r_]
-        keep = pos < kc
-        idx = torch.full((ids.numel(), kc), -1, dtype=torch.int32, device=dev)
-        score = torch.zeros((ids.numel(), kc), dtype=torch.float32, device=dev)
-        idx[r_[keep], pos[keep]] = c_[keep].to(torch.int32)
-        score[r_[keep], pos[keep]] = h[r_[keep], c_[keep]]
-        over = cnt >= kc  # more shows in the band than a list takes: not decided here
-        count = torch.where(over, torch.zeros_like(cnt), cnt).to(torch.int32)
-        rescore_topk(sources, n, offsets, groups, group_weights, norms, TopK(idx, score, count), k, min_similarity, out,
-                     q_row0=q_row0, row_ids=ids, margin=margin)
-        if bool(over.any()):
-            left.append(ids[over])
-        del h, mask
-    return torch.cat(left).contiguous() if left else torch.empty(0, dtype=torch.int32, device=dev)
+    nf = int(rows.numel())
+    cap = int(max(k + 1, min(BAND_LIST_MAX, BAND_BYTES // (8 * max(nf, 1)))))
+    local = rows.long() - q_row0
+    zq = z.index_select(0, rows.long()) if z_q is None else z_q.index_select(0, local)
+    floor = torch.full((nf,), min_similarity - band, dtype=torch.float32, device=dev)
+    t = torch.maximum(floor, cand.score.index_select(0, local)[:, k - 1] - 2.0 * float(margin)).contiguous()
+    idx, score, cnt = band_candidates(z, zq, t, cap, n=n)
+    over = cnt >= cap  # more shows in the band than the list takes: not decided here
+    count = torch.where(over, torch.zeros_like(cnt), cnt)
+    rescore_topk(sources, n, offsets, groups, group_weights, norms, TopK(idx, score, count), k, min_similarity, out,
+                 q_row0=q_row0, row_ids=rows, margin=margin)
+    return rows[over].contiguous()
 
 
 def exact_topk(z: torch.Tensor, sources, offsets, groups, group_weights, k: int, min_similarity: float, *,
@@ -610,9 +619,11 @@ def exact_topk(z: torch.Tensor, sources, offsets, groups, group_weights, k: int,
     matrix) is given when the query side differs from ``z`` -- weights applied on one side only.
     Three stages, each only for the rows the previous one could not certify: (1) the fp32 sweep's
     :func:`candidate_count` best (``cand``; computed here when not given) re-ranked in float64;
-    (2) ``resweep(rows, kc)`` -- by default a plain fp32 sweep of just those rows -- for a longer
-    list (:func:`resweep_candidate_count`), self not excluded, re-ranked; (3) their float64 scores against all shows and an exact
-    selection.  Reads the number of uncertified rows back between stages."""
+    (2) every show inside the band of fp32 scores that can still matter (:func:`_band_stage`), re-ranked:
+    final unless the band holds more shows than a list takes -- or, with ``resweep(rows, kc)`` /
+    ``resweep_k`` given, a longer list from that call or from a plain fp32 sweep of just those rows,
+    self not excluded, re-ranked and certified again; (3) their float64 scores against all shows and
+    an exact selection.  Reads the number of uncertified rows back between stages."""
     n = z.shape[0] if n is None else int(n)
     nq = n - q_row0 if nq is None else int(nq)
     dev = z.device
@@ -644,9 +655,9 @@ def exact_topk(z: torch.Tensor, sources, offsets, groups, group_weights, k: int,
             return out
         rows = flagged[1:1 + nf].sort().values.contiguous()
         kc2 = resweep_candidate_count(k) if resweep_k is None else int(resweep_k)
-        if resweep is None and resweep_k is None and nf <= BAND_ROWS_MAX:
-            # stage 2 for a few rows: all their fp32 scores as a dense strip, every show inside the band
-            # of scores that can still matter as a candidate -- complete by construction
+        if resweep is None and resweep_k is None:
+            # stage 2: every show inside the band of scores that can still matter as a candidate --
+            # a complete list by construction
             out.stats["resweep"] = nf
             rows = _band_stage(z, z_q, sources, n, offsets, groups, group_weights, norms, cand, rows, k, min_similarity,
                                out, q_row0, margin, band)

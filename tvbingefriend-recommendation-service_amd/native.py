@@ -57,6 +57,7 @@ SYMBOLS = (
     "tvbf_block_norms_f64",
     "tvbf_rescore_topk_f64",
     "tvbf_score_rows_f64",
+    "tvbf_band_candidates_f32",
     "tvbf_weighted_sum3_f64",
     "tvbf_stats_workspace_bytes",
     "tvbf_upper_tri_stats_f64",
@@ -230,6 +231,8 @@ def load() -> ctypes.CDLL:
     lib.tvbf_score_rows_f64.restype = c.c_int
     lib.tvbf_score_rows_f64.argtypes = [c.POINTER(Source), c.c_int, i64, i64, c.POINTER(i32), c.c_int,
                                         c.POINTER(i32), c.POINTER(f64), vp, vp, i64, c.c_int, vp, i64, vp]
+    lib.tvbf_band_candidates_f32.restype = c.c_int
+    lib.tvbf_band_candidates_f32.argtypes = [vp, i64, vp, i64, i64, i64, vp, c.c_int, vp, vp, vp, vp]
     lib.tvbf_topk_max_slots.restype = c.c_int
     lib.tvbf_topk_max_slots.argtypes = [c.c_int]
     lib.tvbf_topk_workspace_bytes_for_slots.restype = sz
