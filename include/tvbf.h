@@ -378,17 +378,21 @@ int tvbf_component_scores_f32(const float* Zq, int64_t nq, const float* Zall, in
 
 /*
  * The min_similarity cut of scripts/populate_database.py:204-205 and
- * services/content_based_service.py:220-221 decided in float64, as the reference decides it.
- * tvbf_cosine_topk_f32 compares fp32 scores; a pair whose float64 score meets the threshold
- * exactly (three one-hot metadata matches under the default weights: 0.1 * ((1 + 1 + 1) / 3) == 0.1,
- * kept by the reference) can come out one ulp below it in fp32.  Run the sweep with
- * min_similarity - band (band about 2e-6, well above the fp32 error of a score), compute the
- * per-block cosines with tvbf_component_scores_f32, then call this: every kept pair whose fp32
- * score is below min_similarity + band is re-decided from
+ * services/content_based_service.py:220-221 re-decided in float64 FROM fp32 PER-BLOCK COSINES, for
+ * callers of the fp32 lists.  tvbf_cosine_topk_f32 compares fp32 scores; a pair whose float64 score
+ * meets the threshold exactly (three one-hot metadata matches under the default weights:
+ * 0.1 * ((1 + 1 + 1) / 3) == 0.1, kept by the reference) can come out one ulp below it in fp32.  Run
+ * the sweep with min_similarity - band (band about 2e-6, well above the fp32 error of a score),
+ * compute the per-block cosines with tvbf_component_scores_f32, then call this: every kept pair whose
+ * fp32 score is below min_similarity + band is re-decided from
  *     h = (w[0] * c0 + w[1] * c1) + w[2] * c2,   c_g = mean of the cosines of the blocks of group g
  * in float64 without fused multiply-adds (scripts/populate_database.py:187-192,
- * ml/similarity_computer.py:122-124) and stays iff h >= min_similarity.  Lists stay sorted;
- * idx / score / count / comp are compacted in place (-1 / 0 in freed slots).
+ * ml/similarity_computer.py:122-124) and stays iff h >= min_similarity.  The decision equals the
+ * reference's when the block cosines are exact in fp32 (one-hot and other 0/1 blocks); otherwise it
+ * carries their fp32 error (about 1e-7), and the kept pairs keep their fp32 scores.  The reference's
+ * decision for ANY pair -- and float64 scores -- come from tvbf_rescore_topk_f64, which the Python
+ * facades use.  Lists stay sorted; idx / score / count / comp are compacted in place (-1 / 0 in
+ * freed slots).
  *
  *   idx, score, count   device, outputs of tvbf_cosine_topk_f32 (nq x k, nq x k, nq)
  *   comp                device, nq x k x nb fp32 from tvbf_component_scores_f32 (plain cosines)

@@ -400,7 +400,9 @@ THRESHOLD_BAND = 2e-6
 
 def refine_min_similarity(top: TopK, comp: torch.Tensor, groups, group_weights, min_similarity: float,
                           band: float = THRESHOLD_BAND) -> None:
-    """The reference's ``score < min_similarity`` test in float64 for the pairs of ``top`` whose fp32
+    """The reference's ``score < min_similarity`` test re-decided in float64 from fp32 per-block
+    cosines (exact when those are exact, e.g. one-hot blocks; :func:`exact_topk` decides from float64
+    cosines) for the pairs of ``top`` whose fp32
     score lies within ``band`` of the threshold (in place; ``top`` must come from a sweep run with
     ``min_similarity - band``, ``comp`` (nq, k, nb) are its plain per-block cosines).  ``groups[b]``
     in {0: genre, 1: text, 2: metadata} and the three ``group_weights`` spell the reference's
