@@ -5,8 +5,9 @@
 
 One "step" = one pass of the hot path over the whole synthetic catalogue, as the
 drop-in runs it (--path exact, the default): build the normalised, weighted
-matrix from the stored features (K1) -> [all-gather of the normalised shards
-when N > 1] -> fused all-pairs similarity + per-row top-(K + slack) in fp32
+matrix from the stored features (K1; when N > 1 every rank builds all rows from
+the features resident on it, or with --z-exchange gather its own shard followed
+by one all-gather) -> fused all-pairs similarity + per-row top-(K + slack) in fp32
 (K2-K4) -> float64 re-rank of the candidates from the stored features (order,
 scores, threshold cut and per-block scores of the reference's float64
 arithmetic; rows that cannot be certified get a longer list or a scan).
@@ -57,6 +58,11 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline sample")
     ap.add_argument("--check", action="store_true",
                     help="after the timed steps, recompute this rank's lists with the plain sweep and compare bitwise")
+    ap.add_argument("--z-exchange", choices=["auto", "local", "gather"], default="auto",
+                    help="several GPUs: how a rank gets the normalised rows of the other shards.  local: it builds "
+                         "them itself from the stored features, which are resident on every rank (auto on the exact "
+                         "path, whose re-rank needs them there anyway); gather: one all-gather of the shards "
+                         "(auto on the fp32 path)")
     ap.add_argument("--sweep", choices=["auto", "plain", "symmetric"], default="auto",
                     help="single GPU: 'symmetric' computes every pair of shows once (identical lists); "
                          "auto takes it whenever the library accepts the shape")
@@ -295,8 +301,17 @@ def main():
     exact = args.path == "exact"
     kc = engine.candidate_count(args.k) if exact else args.k       # candidates per show the sweep collects
     sweep_min = min_sim - engine.THRESHOLD_BAND if exact else min_sim
-    z_shard = torch.empty((shard.per_rank, ld), dtype=torch.float32, device=dev)
-    z_all = z_shard if world == 1 else torch.empty((shard.padded_total, ld), dtype=torch.float32, device=dev)
+    # Several ranks: where the stored features of all shows are resident on every rank -- the exact
+    # path needs them for the re-rank -- each rank builds the whole normalised matrix itself (K1 over
+    # all rows, 0.15 ms at the headline size) and no all-gather of Z is needed; otherwise (or with
+    # --z-exchange gather) each rank builds its shard and one RCCL all-gather distributes them.
+    z_local = world > 1 and (args.z_exchange == "local" or (args.z_exchange == "auto" and exact))
+    if z_local:
+        z_all = torch.zeros((shard.padded_total, ld), dtype=torch.float32, device=dev)
+        z_shard = z_all[rank * shard.per_rank:(rank + 1) * shard.per_rank]
+    else:
+        z_shard = torch.empty((shard.per_rank, ld), dtype=torch.float32, device=dev)
+        z_all = z_shard if world == 1 else torch.empty((shard.padded_total, ld), dtype=torch.float32, device=dev)
     nq = shard.rows
     groups = [0, 1, 2][: len(weights)]
     gw = (list(weights) + [0.0, 0.0])[:3]
@@ -395,9 +410,17 @@ def main():
         def wait(self):
             z_all.copy_(self.full)
 
+    class Resident:
+        """Z of all shows was built on this rank: nothing to wait for."""
+
+        def wait(self):
+            pass
+
     def start_gather():
         if world == 1:
             return None
+        if z_local:
+            return Resident()
         if args.backend == "nccl":
             return dist.all_gather_into_tensor(z_all, z_shard, async_op=True)
         return HostGather()
@@ -417,7 +440,9 @@ def main():
         ms_sweep = sweep_min if path_exact else min_sim
         res = out if kk == kc else out_k
         mark("start")
-        if nq:  # the drop-in's K1: this rank's rows of Z assembled from the stored arrays
+        if z_local:  # the drop-in's K1 over the stored arrays of all shows
+            engine.assemble_normalize(src_all, args.n, offsets, scales, out=z_all[: args.n])
+        elif nq:  # this rank's rows of Z; the others arrive with the all-gather
             engine.assemble_normalize(src_shard, nq, offsets, scales, out=z_shard[:nq])
         mark("k1")
         work = start_gather()
@@ -436,7 +461,8 @@ def main():
             bounds_all = sharding.gather_words(job.own_bounds(), world)
             mark("bounds_gather")
             work.wait()
-            mark("gather_wait")
+            if not z_local:
+                mark("gather_wait")
             job.phase_half(z_all, bounds_all)
             mark("half")
             packed = sharding.pack_lists_and_flags(job.lists_for_peers(bounds_all), job.flag, shard)
@@ -457,7 +483,8 @@ def main():
             mark("own")
             if work is not None:
                 work.wait()
-                mark("gather_wait")
+                if not z_local:
+                    mark("gather_wait")
                 session.accumulate((z_all[after[0]:], after[1], after[0]), (z_all, before[1], before[0]))
                 mark("rest")
             session.finish(res)
@@ -585,8 +612,12 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": workload, "rows_per_gpu": per_rank_rows,
-                   "parallelism": (f"row-shard x{world} + all-gather ({args.backend})"
-                                   + (" + all-to-all of column-side lists" if symmetric else "")) if world > 1 else "single GPU",
+                   "parallelism": (f"row-shard x{world}, "
+                                   + ("Z built on every rank from the resident stored features (no all-gather of Z)"
+                                      if z_local else "all-gather of the normalised shards")
+                                   + (" + all-gather of bound keys + all-to-all of column-side lists" if symmetric else "")
+                                   + f" ({args.backend})") if world > 1 else "single GPU",
+                   "z_exchange": ("local" if z_local else "gather") if world > 1 else None,
                    "sweep": "symmetric: every unordered pair of shows computed once, both shows' lists fed from it; "
                             "roofline.achieved counts the flops executed" if symmetric else "plain: every ordered pair computed"},
         "topk_build_time_s": elapsed / args.steps,

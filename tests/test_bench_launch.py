@@ -36,15 +36,20 @@ def test_launcher_returns_the_failure_of_its_ranks():
 
 
 @pytest.mark.gpu
-def test_bench_gpus_2_launches_itself(device):
+@pytest.mark.parametrize("z_exchange", ["auto", "gather"])
+def test_bench_gpus_2_launches_itself(device, z_exchange):
     """`python bench.py --gpus 2` with no WORLD_SIZE: two rank processes share the one GPU (gloo
-    rehearsal), rank 0 prints one JSON line with n_gpus 2, every rank's lists equal the plain sweep."""
+    rehearsal), rank 0 prints one JSON line with n_gpus 2, every rank's lists equal the plain sweep --
+    with the normalised matrix built on every rank (the exact path's default) and with the shards
+    all-gathered."""
     res = _run("--gpus", "2", "--backend", "gloo", "--shows", "8192", "--steps", "2", "--warmup", "1", "--check",
-               "--no-cpu-baseline")
+               "--no-cpu-baseline", "--z-exchange", z_exchange)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["value"] > 0
     assert 0 < line["roofline"]["frac"] <= 1.0
+    assert line["config"]["z_exchange"] == ("local" if z_exchange == "auto" else "gather")
+    assert ("gather_wait_ms" in line["phases"]) == (z_exchange == "gather")
     assert res.stderr.count("lists equal to the plain sweep: True") == 2

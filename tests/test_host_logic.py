@@ -312,7 +312,7 @@ def _ordered_f32(m):
     return u.view(np.float32)
 
 
-def _sym_worker(rank, world, port, n, k, min_sim, ret):
+def _sym_worker(rank, world, port, n, k, min_sim, ret, resident=False):
     """One gloo rank of sharded_topk_symmetric: the real partition logic and collectives around a
     CPU stand-in for the device job (float64 products, keys in the device format)."""
     import torch
@@ -426,8 +426,16 @@ def _sym_worker(rank, world, port, n, k, min_sim, ret):
             holder["job"] = OracleJob(*a)
             return holder["job"]
 
-        top, z_all = sharding.sharded_topk_symmetric(torch.from_numpy(xs), offsets, scales, sh, k, min_sim,
-                                                     normalize_fn=normalize_fn, job_fn=job_fn)
+        if resident:  # every rank holds all features: it builds all normalised rows itself, no all-gather of them
+            xa = np.zeros((sh.padded_total, x.shape[1]), np.float32)
+            xa[:n] = x
+            z_res = normalize_fn(torch.from_numpy(xa), offsets, scales)
+            top, z_all = sharding.sharded_topk_symmetric_z(z_res[rank * sh.per_rank:(rank + 1) * sh.per_rank], sh, k,
+                                                           min_sim, job_fn=job_fn, z_all=z_res)
+            assert z_all is z_res
+        else:
+            top, z_all = sharding.sharded_topk_symmetric(torch.from_numpy(xs), offsets, scales, sh, k, min_sim,
+                                                         normalize_fn=normalize_fn, job_fn=job_fn)
         entries = torch.tensor([holder["job"].entries], dtype=torch.int64)
         dist.all_reduce(entries)
         idx = sharding.gather_lists(top.idx, sh)
@@ -440,11 +448,13 @@ def _sym_worker(rank, world, port, n, k, min_sim, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,world", [(101, 2), (64, 2), (130, 3), (150, 4)])
-def test_sharded_topk_symmetric_gloo(pkg, n, world):
+@pytest.mark.parametrize("n,world,resident", [(101, 2, False), (64, 2, False), (130, 3, False), (150, 4, False),
+                                              (101, 2, True), (150, 4, True)])
+def test_sharded_topk_symmetric_gloo(pkg, n, world, resident):
     """Real ranks over gloo: the partition (half peers, split partner block), the all-gathers, the
     all-to-all of lists and the flag reduction hand every pair of shows to exactly one rank, and
-    the merged lists equal the single-process result."""
+    the merged lists equal the single-process result -- with the normalised shards all-gathered,
+    and with all normalised rows built on every rank (``resident``)."""
     import torch.multiprocessing as mp
 
     from tvbingefriend_recommendation_service_amd import sharding
@@ -454,7 +464,7 @@ def test_sharded_topk_symmetric_gloo(pkg, n, world):
     ret = mgr.dict()
     port = _free_port()
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_sym_worker, args=(r, world, port, n, k, min_sim, ret)) for r in range(world)]
+    procs = [ctx.Process(target=_sym_worker, args=(r, world, port, n, k, min_sim, ret, resident)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

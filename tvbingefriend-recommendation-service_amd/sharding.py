@@ -104,9 +104,11 @@ def sharded_topk(x_shard: torch.Tensor, offsets, scales, shard: Shard, k: int, m
 
 
 def sharded_topk_z(z_shard: torch.Tensor, shard: Shard, k: int, min_similarity: float, group=None, session_fn=None,
-                   collective=None):
+                   collective=None, z_all: torch.Tensor | None = None):
     """:func:`sharded_topk` from the rank's normalised rows ``z_shard`` ((per_rank, ld), padding
-    rows zero) on: all-gather, own columns meanwhile, the rest, merge."""
+    rows zero) on: all-gather, own columns meanwhile, the rest, merge.  ``z_all`` ((padded_total, ld),
+    rank-major, padding rows zero): the normalised rows of ALL shows when the rank already holds them
+    (it built them itself from features that are resident on every rank) -- no all-gather then."""
     if session_fn is None:
         from . import engine
 
@@ -121,6 +123,14 @@ def sharded_topk_z(z_shard: torch.Tensor, shard: Shard, k: int, min_similarity: 
         session = session_fn(z_shard, shard.rows, 0, k, min_similarity)
         session.accumulate((z_shard, shard.rows, 0))
         return session.finish(), z_shard
+    if z_all is not None:
+        if z_all.shape != (shard.padded_total, z_shard.shape[1]):
+            raise ValueError("z_all must hold per_rank * world rows")
+        own, after, before = column_pieces(shard)
+        session = session_fn(z_shard, shard.rows, shard.row0, k, min_similarity)
+        session.accumulate((z_shard, own[1], own[0]))
+        session.accumulate((z_all[after[0]:], after[1], after[0]), (z_all, before[1], before[0]))
+        return session.finish(), z_all
     z_all = torch.empty((shard.padded_total, z_shard.shape[1]), dtype=z_shard.dtype, device=z_shard.device)
     if _via_host(z_shard, group):  # gloo ranks that use GPUs: through host memory, synchronously
         host = z_shard.cpu()
@@ -410,12 +420,17 @@ def sharded_topk_symmetric(x_shard: torch.Tensor, offsets, scales, shard: Shard,
 
 
 def sharded_topk_symmetric_z(z_shard: torch.Tensor, shard: Shard, k: int, min_similarity: float, group=None,
-                             job_fn=None):
+                             job_fn=None, z_all: torch.Tensor | None = None):
     """:func:`sharded_topk_symmetric` from the rank's normalised rows ``z_shard`` ((per_rank, ld),
-    padding rows zero) on."""
+    padding rows zero) on.  ``z_all``: as in :func:`sharded_topk_z` -- the Z all-gather is left out,
+    the exchanges of the symmetric route (bound keys, column-side lists) stay."""
     job_fn = job_fn or SymmetricShardJob
     if z_shard.shape[0] != shard.per_rank:
         raise ValueError("z_shard must be padded to per_rank rows")
+    if z_all is not None:
+        if z_all.shape != (shard.padded_total, z_shard.shape[1]):
+            raise ValueError("z_all must hold per_rank * world rows")
+        return _symmetric_exchange(job_fn, z_shard, z_all, None, shard, k, min_similarity, group)
     z_all = torch.empty((shard.padded_total, z_shard.shape[1]), dtype=z_shard.dtype, device=z_shard.device)
     host_route = _via_host(z_shard, group)
     if host_route:
@@ -428,6 +443,12 @@ def sharded_topk_symmetric_z(z_shard: torch.Tensor, shard: Shard, k: int, min_si
         work = dist.all_gather_into_tensor(z_all, z_shard, group=group, async_op=True)
     else:
         work = dist.all_gather(list(z_all.chunk(shard.world, dim=0)), z_shard, group=group, async_op=True)
+    return _symmetric_exchange(job_fn, z_shard, z_all, work, shard, k, min_similarity, group)
+
+
+def _symmetric_exchange(job_fn, z_shard, z_all, work, shard: Shard, k: int, min_similarity: float, group):
+    """The phases of the symmetric sharded sweep around their collectives; ``work``: the handle of
+    the Z all-gather in flight (None: z_all is complete)."""
     if job_fn is SymmetricShardJob and z_shard.is_cuda:
         from . import engine
 
