@@ -22,6 +22,7 @@
 #include <float.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "tvbf.h"
 
@@ -53,6 +54,16 @@ __device__ inline double wave_sum64(double v) {
     // v_l + v_(l^s) is the same sum in both lanes, so all 64 lanes end with identical bits
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
+    return v;
+}
+
+// The same over every aligned group of G lanes (lane ^ s stays inside the group for s < G): the G
+// lanes of a group end with identical bits, and groups whose lanes are switched off do not matter
+// to the others.
+template <int G>
+__device__ inline double group_sum64(double v) {
+#pragma unroll
+    for (int s = G / 2; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
     return v;
 }
 
@@ -128,8 +139,10 @@ __device__ inline void build_scaled_image_wg(const RSources& src, const RBlocks&
     __syncthreads();
 }
 
-// sum over the columns [lo, hi) of img[c] * (stored value of show j at column c), wave-reduced
-__device__ inline double block_dot(const RSources& src, int lo, int hi, int64_t j, const double* img, int lane) {
+// sum over the columns [lo, hi) of img[c] * (stored value of show j at column c), by the G lanes of
+// one group (gl: the lane's place in it), reduced over the group
+template <int G>
+__device__ inline double block_dot(const RSources& src, int lo, int hi, int64_t j, const double* img, int gl) {
     double acc = 0.0;
     for (int s = 0; s < src.ns; ++s) {
         const tvbf_source& q = src.s[s];
@@ -140,7 +153,7 @@ __device__ inline double block_dot(const RSources& src, int lo, int hi, int64_t 
             ((uintptr_t)q.data & 15) == 0) {
             // wide fp32 blocks (a packed feature matrix): 16 bytes per lane and load
             const float* rowp = static_cast<const float*>(q.data) + j * q.ld + (a - q.z_col);
-            for (int c = 4 * lane; c < e - a; c += 256) {
+            for (int c = 4 * gl; c < e - a; c += 4 * G) {
                 const float4 v = *reinterpret_cast<const float4*>(rowp + c);
                 const double* m = img + a + c;
                 acc = fma(m[0], (double)v.x, acc);
@@ -150,10 +163,10 @@ __device__ inline double block_dot(const RSources& src, int lo, int hi, int64_t 
             }
         } else if (q.kind <= TVBF_SRC_DENSE_U8) {
             const int64_t base = j * q.ld - q.z_col;
-            for (int c = a + lane; c < e; c += 64) acc = fma(img[c], dense_at64(q.kind, q.data, base + c), acc);
+            for (int c = a + gl; c < e; c += G) acc = fma(img[c], dense_at64(q.kind, q.data, base + c), acc);
         } else {
             const int64_t p0 = index_at64(q.indptr, q.index64, j), p1 = index_at64(q.indptr, q.index64, j + 1);
-            for (int64_t p = p0 + lane; p < p1; p += 64) {
+            for (int64_t p = p0 + gl; p < p1; p += G) {
                 const int64_t ci = index_at64(q.indices, q.index64, p);
                 if (ci < 0 || ci >= q.width) continue;
                 const int c = q.z_col + (int)ci;
@@ -162,18 +175,22 @@ __device__ inline double block_dot(const RSources& src, int lo, int hi, int64_t 
             }
         }
     }
-    return wave_sum64(acc);
+    return group_sum64<G>(acc);
 }
 
 // The reference's score of the pair (image's show, j): per block the cosine, per group the mean of
 // its blocks' cosines ((p + t + l) / 3, scripts/populate_database.py:187), then
 // (wg * g + wt * t) + wm * m with every product and sum rounded on its own (:190-192,
-// ml/similarity_computer.py:122-124).  All lanes return the same bits.
+// ml/similarity_computer.py:122-124).  One group of G lanes per pair -- a stored row of the
+// reference's catalogue is a few dozen entries per block, so a whole wavefront per pair leaves most
+// lanes idle and keeps only one gather in flight where 64 / G fit; all lanes of the group return
+// the same bits, and the bits do not depend on G's neighbours in the wavefront.
+template <int G>
 __device__ inline double pair_score(const RSources& src, const RBlocks& bd, const double* __restrict__ norms,
-                                    int64_t j, const double* img, int lane, double comp[3]) {
+                                    int64_t j, const double* img, int gl, double comp[3]) {
     double g0 = 0.0, g1 = 0.0, g2 = 0.0;
     for (int b = 0; b < bd.nb; ++b) {
-        const double cosb = block_dot(src, bd.off[b], bd.off[b + 1], j, img, lane) / norms[j * bd.nb + b];
+        const double cosb = block_dot<G>(src, bd.off[b], bd.off[b + 1], j, img, gl) / norms[j * bd.nb + b];
         const int g = bd.group[b];
         if (g == 0) g0 = g0 + cosb;
         else if (g == 1) g1 = g1 + cosb;
@@ -209,8 +226,9 @@ __global__ __launch_bounds__(64) void block_norms_f64_kernel(RSources src, RBloc
     }
 }
 
-constexpr int RESCORE_WAVES = 4;  // wavefronts per show: its candidates are dealt out to them in turn
+constexpr int RESCORE_WAVES = 4;  // wavefronts per show: its candidates are dealt out to their lane groups in turn
 
+template <int G>
 __global__ __launch_bounds__(64 * RESCORE_WAVES) void rescore_topk_kernel(
     RSources src, RBlocks bd, int d, const double* __restrict__ norms, const int32_t* __restrict__ row_ids,
     int64_t nq, int64_t q_row0, const int32_t* __restrict__ cand_idx, const float* __restrict__ cand_score,
@@ -232,15 +250,17 @@ __global__ __launch_bounds__(64 * RESCORE_WAVES) void rescore_topk_kernel(
 
     int cnt = cand_count[r];
     if (cnt > kc) cnt = kc;
-    for (int s = wave; s < cnt; s += RESCORE_WAVES) {
+    constexpr int GROUPS = 64 / G;  // pairs a wavefront scores at a time
+    const int gl = lane & (G - 1);
+    for (int s = wave * GROUPS + lane / G; s < cnt; s += RESCORE_WAVES * GROUPS) {
         const int64_t j = cand_idx[r * kc + s];
         if (j < 0 || (exclude_self && j == show)) {
-            if (lane == 0) col[s] = -1, sc[s] = 0.0;
+            if (gl == 0) col[s] = -1, sc[s] = 0.0;
             continue;
         }
         double comp[3];
-        const double h = pair_score(src, bd, norms, j, img, lane, comp);
-        if (lane == 0) {
+        const double h = pair_score<G>(src, bd, norms, j, img, gl, comp);
+        if (gl == 0) {
             // the reference leaves the loop at the first score below the threshold (:204-205)
             col[s] = h >= min_similarity ? (int32_t)j : -1;
             sc[s] = h;
@@ -301,7 +321,9 @@ __global__ __launch_bounds__(64 * RESCORE_WAVES) void rescore_topk_kernel(
 }
 
 // H[r, j] = the float64 score of show row_ids[r] against show j (-inf at j == the show itself when
-// exclude_self).  grid (column chunks, rows), four wavefronts take the chunk's columns in turn.
+// exclude_self).  grid (column chunks, rows), the lane groups of four wavefronts take the chunk's
+// columns in turn.
+template <int G>
 __global__ __launch_bounds__(256) void score_rows_f64_kernel(RSources src, RBlocks bd, int64_t n, int d,
                                                              const double* __restrict__ norms,
                                                              const int32_t* __restrict__ row_ids, int exclude_self,
@@ -314,10 +336,12 @@ __global__ __launch_bounds__(256) void score_rows_f64_kernel(RSources src, RBloc
     int64_t j1 = j0 + cols_per_wg;
     if (j1 > n) j1 = n;
     double* out = H + (int64_t)blockIdx.y * ldh;
-    for (int64_t j = j0 + wave; j < j1; j += 4) {
+    constexpr int GROUPS = 64 / G;
+    const int gl = lane & (G - 1);
+    for (int64_t j = j0 + wave * GROUPS + lane / G; j < j1; j += 4 * GROUPS) {
         double comp[3];
-        const double h = pair_score(src, bd, norms, j, img_lds, lane, comp);
-        if (lane == 0) out[j] = (exclude_self && j == show) ? -INFINITY : h;
+        const double h = pair_score<G>(src, bd, norms, j, img_lds, gl, comp);
+        if (gl == 0) out[j] = (exclude_self && j == show) ? -INFINITY : h;
     }
 }
 
@@ -364,6 +388,22 @@ int fill_tables(const tvbf_source* sources, int ns, int64_t n, int64_t d, const 
         src->s[s] = q;
     }
     return TVBF_OK;
+}
+
+// Lanes per pair.  Measured at 100,000 shows x 1024 columns with 28 candidates per show, the re-rank
+// stages together take 6.8 / 5.5 / 4.8 / 4.5 / 4.9 ms with 64 / 32 / 16 / 8 / 4 lanes on a catalogue in
+// the reference's stored form (narrow dense blocks, sparse text) and 2.6 / 2.3 / 2.2 ms with 64 / 16 / 8
+// on one packed fp32 matrix (16-byte loads): eight lanes, i.e. eight gathers in flight per wavefront.
+int lanes_per_pair(const RSources& src) {
+    // TVBF_RESCORE_LANES (4, 8, 16, 32 or 64) overrides the choice in a process started with TVBF_TUNING=1
+    static const int forced = [] {
+        const char* t = getenv("TVBF_TUNING");
+        const char* e = (t && t[0] == '1') ? getenv("TVBF_RESCORE_LANES") : nullptr;
+        const int v = e ? atoi(e) : 0;
+        return (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) ? v : 0;
+    }();
+    (void)src;
+    return forced ? forced : 8;
 }
 
 template <typename K>
@@ -413,10 +453,19 @@ int tvbf_rescore_topk_f64(const tvbf_source* sources, int ns, int64_t n, int64_t
         return tvbf_fail(TVBF_E_BAD_ARG, "min_similarity / margin is NaN");
     if (nq == 0) return TVBF_OK;
     const size_t lds = ((size_t)d + 4 * (size_t)kc) * sizeof(double) + (size_t)kc * sizeof(int32_t);
-    if (int rc = allow_lds(rescore_topk_kernel, lds)) return rc;
-    hipLaunchKernelGGL(rescore_topk_kernel, dim3((unsigned)nq), dim3(64 * RESCORE_WAVES), lds, (hipStream_t)stream, src,
-                       bd, (int)d, norms, row_ids, nq, q_row0, cand_idx, cand_score, cand_count, kc, k, min_similarity,
-                       margin, exclude_self, out_idx, out_score, out_comp, out_count, out_row0, flagged);
+    auto launch = [&](auto kernel) -> int {
+        if (int rc = allow_lds(kernel, lds)) return rc;
+        hipLaunchKernelGGL(kernel, dim3((unsigned)nq), dim3(64 * RESCORE_WAVES), lds, (hipStream_t)stream, src, bd,
+                           (int)d, norms, row_ids, nq, q_row0, cand_idx, cand_score, cand_count, kc, k,
+                           min_similarity, margin, exclude_self, out_idx, out_score, out_comp, out_count, out_row0,
+                           flagged);
+        return TVBF_OK;
+    };
+    const int g = lanes_per_pair(src);
+    if (int rc = g == 64 ? launch(rescore_topk_kernel<64>) : g == 32 ? launch(rescore_topk_kernel<32>)
+                 : g == 16 ? launch(rescore_topk_kernel<16>) : g == 4 ? launch(rescore_topk_kernel<4>)
+                 : launch(rescore_topk_kernel<8>))
+        return rc;
     HIP_TRY(hipGetLastError());
     return TVBF_OK;
 }
@@ -431,11 +480,19 @@ int tvbf_score_rows_f64(const tvbf_source* sources, int ns, int64_t n, int64_t d
     if (nr < 0 || nr > 65535 || ldh < n) return tvbf_fail(TVBF_E_BAD_ARG, "need 0 <= nr <= 65535 and ldh >= n");
     if (nr == 0 || n == 0) return TVBF_OK;
     const size_t lds = (size_t)d * sizeof(double);
-    if (int rc = allow_lds(score_rows_f64_kernel, lds)) return rc;
     const int cols_per_wg = 2048;
     const int64_t chunks = (n + cols_per_wg - 1) / cols_per_wg;
-    hipLaunchKernelGGL(score_rows_f64_kernel, dim3((unsigned)chunks, (unsigned)nr), dim3(256), lds,
-                       (hipStream_t)stream, src, bd, n, (int)d, norms, row_ids, exclude_self, cols_per_wg, H, ldh);
+    auto launch = [&](auto kernel) -> int {
+        if (int rc = allow_lds(kernel, lds)) return rc;
+        hipLaunchKernelGGL(kernel, dim3((unsigned)chunks, (unsigned)nr), dim3(256), lds, (hipStream_t)stream, src, bd,
+                           n, (int)d, norms, row_ids, exclude_self, cols_per_wg, H, ldh);
+        return TVBF_OK;
+    };
+    const int g = lanes_per_pair(src);
+    if (int rc = g == 64 ? launch(score_rows_f64_kernel<64>) : g == 32 ? launch(score_rows_f64_kernel<32>)
+                 : g == 16 ? launch(score_rows_f64_kernel<16>) : g == 4 ? launch(score_rows_f64_kernel<4>)
+                 : launch(score_rows_f64_kernel<8>))
+        return rc;
     HIP_TRY(hipGetLastError());
     return TVBF_OK;
 }
