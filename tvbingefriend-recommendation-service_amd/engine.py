@@ -465,25 +465,34 @@ def resweep_candidate_count(k: int) -> int:
     return max(int(k), native.TVBF_MAX_K)
 
 
-def block_norms(sources, n: int, offsets, *, check_finite: bool = True) -> torch.Tensor:
+def raise_if_not_finite(bits: int) -> None:
+    """sklearn's input validation messages for the flag word of tvbf_block_norms_f64."""
+    if bits & 1:
+        raise ValueError("Input contains NaN.")
+    if bits & 2:
+        raise ValueError("Input contains infinity or a value too large for dtype('float64').")
+
+
+def block_norms(sources, n: int, offsets, *, check_finite: bool = True, finite_flag: torch.Tensor | None = None) -> torch.Tensor:
     """(n, nb) float64 L2 norms of every show's feature blocks (a zero block counts as 1, as in
     sklearn's normalize).  With ``check_finite`` a NaN or infinite stored value raises ValueError
-    with sklearn's message (the reference's cosine_similarity validates its input; synchronises)."""
+    with sklearn's message (the reference's cosine_similarity validates its input; synchronises).
+    ``finite_flag`` (int32, one zeroed word on the device): the kernel's flag word is left there for
+    the caller to read with its next read-back and hand to :func:`raise_if_not_finite` -- no
+    synchronisation here."""
     arr, device = _source_array(sources, n)
     nb = len(offsets) - 1
     off = (ctypes.c_int32 * (nb + 1))(*[int(o) for o in offsets])
     norms = torch.empty((n, nb), dtype=torch.float64, device=device)
-    flag = torch.zeros(1, dtype=torch.int32, device=device) if check_finite else None
+    flag = finite_flag
+    if flag is None and check_finite:
+        flag = torch.zeros(1, dtype=torch.int32, device=device)
     with torch.cuda.device(device):
         rc = native.load().tvbf_block_norms_f64(arr, len(sources), n, int(offsets[-1]), off, nb, norms.data_ptr(),
                                                 flag.data_ptr() if flag is not None else None, _stream_ptr())
     native.check(rc, "tvbf_block_norms_f64")
-    if flag is not None:
-        bits = int(flag.item())
-        if bits & 1:
-            raise ValueError("Input contains NaN.")
-        if bits & 2:
-            raise ValueError("Input contains infinity or a value too large for dtype('float64').")
+    if flag is not None and finite_flag is None:
+        raise_if_not_finite(int(flag.item()))
     return norms
 
 
@@ -606,6 +615,8 @@ def _band_stage(z, z_q, sources, n, offsets, groups, group_weights, norms, cand,
     count = torch.where(over, torch.zeros_like(cnt), cnt)
     rescore_topk(sources, n, offsets, groups, group_weights, norms, TopK(idx, score, count), k, min_similarity, out,
                  q_row0=q_row0, row_ids=rows, margin=margin)
+    if not bool(over.any().item()):  # the usual case: one scalar read back, no compaction
+        return rows[:0]
     return rows[over].contiguous()
 
 
@@ -629,13 +640,19 @@ def exact_topk(z: torch.Tensor, sources, offsets, groups, group_weights, k: int,
     n = z.shape[0] if n is None else int(n)
     nq = n - q_row0 if nq is None else int(nq)
     dev = z.device
+    # one int32 buffer for everything the host reads back: [0] the finite-check word of the norms
+    # kernel, [1] the number of flagged shows, [2:] the flagged shows -- one read-back for both
+    words = torch.zeros(2 + nq, dtype=torch.int32, device=dev)
+    checked = norms is None and check_finite
     if norms is None:
-        norms = block_norms(sources, n, offsets, check_finite=check_finite)
+        norms = block_norms(sources, n, offsets, check_finite=False, finite_flag=words[:1] if checked else None)
     out = TopK64(torch.empty((nq, k), dtype=torch.int32, device=dev), torch.empty((nq, k), dtype=torch.float64, device=dev),
                  torch.empty((nq,), dtype=torch.int32, device=dev), torch.empty((nq, k, 3), dtype=torch.float64, device=dev),
                  {"candidates": 0, "resweep": 0, "scan": 0})
     if k > native.TVBF_MAX_K:
         # longer lists than the sweeps keep: every row goes straight to the scan of all shows
+        if checked:
+            raise_if_not_finite(int(words[0].item()))
         rows = torch.arange(q_row0, q_row0 + nq, dtype=torch.int32, device=dev)
         nf = nq
     else:
@@ -649,10 +666,12 @@ def exact_topk(z: torch.Tensor, sources, offsets, groups, group_weights, k: int,
                 cand = cosine_topk(z, kc, min_similarity - band, q_row0=q_row0, nq=nq, n=n)
         kc = cand.idx.shape[1]
         out.stats["candidates"] = kc
-        flagged = torch.zeros(1 + nq, dtype=torch.int32, device=dev)
+        flagged = words[1:]
         rescore_topk(sources, n, offsets, groups, group_weights, norms, cand, k, min_similarity, out, q_row0=q_row0,
                      margin=margin, flagged=flagged)
-        nf = int(flagged[0].item())
+        bits, nf = words[:2].tolist()
+        if checked:
+            raise_if_not_finite(bits)  # sklearn validates before any arithmetic; nothing was returned yet
         if nf == 0:
             return out
         rows = flagged[1:1 + nf].sort().values.contiguous()

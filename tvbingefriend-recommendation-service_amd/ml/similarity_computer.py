@@ -270,7 +270,6 @@ class SimilarityComputer:
             return self._topk_sharded(features, k, min_similarity, variant, None if group is True else group)
         # the stored arrays go to the device as they are (CSR text stays CSR); Z is built there
         dev_sources, layout, n = self._device_sources(features, variant)
-        norms = engine.block_norms(dev_sources, n, layout.offsets)  # raises on NaN / infinity, as sklearn does
         if min(layout.weights) >= 0:
             # Z = [sqrt(w_b) * unit block]: Z Z^T is the hybrid matrix, every pair computed once
             z = engine.assemble_normalize(dev_sources, n, layout.offsets, layout.scales())
@@ -280,8 +279,9 @@ class SimilarityComputer:
             # query side only (a plain sweep; the reference accepts any weights, ml/similarity_computer.py:112-124)
             z = engine.assemble_normalize(dev_sources, n, layout.offsets, [1.0] * layout.nb)
             z_q = engine.assemble_normalize(dev_sources, n, layout.offsets, [float(w) for w in layout.weights])
+        # the float64 norms are computed inside; NaN / infinity raise ValueError there, as sklearn does
         top = engine.exact_topk(z, dev_sources, layout.offsets, layout.groups, self.group_weights(variant),
-                                k, min_similarity, n=n, norms=norms, z_q=z_q)
+                                k, min_similarity, n=n, z_q=z_q)
         self.last_topk_stats = dict(top.stats)
         return TopKResult(top.idx.cpu().numpy(), top.score.cpu().numpy(), top.count.cpu().numpy(),
                           top.comp.cpu().numpy())
