@@ -196,3 +196,46 @@ def test_negative_weights_and_long_lists(pkg, device):
         print(f"weights {weights} {variant} k={k}: {stats}, stages {st}")
         if k > 100:
             assert st["scan"] == n and st["candidates"] == 0
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 130])
+def test_small_and_degenerate_catalogues(pkg, device, n):
+    """Catalogues smaller than K and than a tile, shows with all-zero blocks (sklearn's norm guard: the
+    block's cosines are 0), empty text rows, duplicated shows (exact ties at 1.0), and thresholds that
+    keep everything or nothing: lists, counts and float64 scores are the oracle's."""
+    feats = hybrid_like_blocks(max(n, 4), seed=77 + n, d_genre=12, d_text=40, as_features=True)
+    feats = {name: a[:n] for name, a in feats.items()}
+    genre = np.array(feats["genre_features"])
+    text = sp.lil_matrix(feats["text_features"].astype(np.float64))
+    if n >= 2:
+        genre[0] = 0                      # a show without genres: its genre cosines are 0
+        text[1] = 0                       # a show without text
+    if n >= 17:
+        genre[5], genre[6] = genre[4], genre[4]   # three shows equal in every block: ties at the top
+        text[5], text[6] = text[4], text[4]
+        for name in ("platform_features", "type_features", "language_features"):
+            a = np.array(feats[name])
+            a[5], a[6] = a[4], a[4]
+            feats[name] = a
+    feats["genre_features"], feats["text_features"] = genre, sp.csr_matrix(text)
+    weights = (0.4, 0.5, 0.1)
+    for variant in ("populate", "computer"):
+        h, _ = _oracle_hybrid(feats, weights, variant)
+        for k, ms in ((20, 0.1), (3, -1.0), (5, 0.999), (4, 1.5)):
+            res, st = _exact(pkg, device, feats, weights, variant, k, ms)
+            assert res.idx.shape == (n, k) and res.score.dtype == np.float64
+            hh = h.copy()
+            np.fill_diagonal(hh, -np.inf)
+            near = np.abs(hh - ms) <= REFINED_TOL   # a pair this close to the threshold may fall either way
+            lo = np.minimum(k, ((hh >= ms) & ~near).sum(1))
+            hi = np.minimum(k, ((hh >= ms) | near).sum(1))
+            assert np.all(res.count >= lo) and np.all(res.count <= hi), (n, variant, k, ms)
+            check_topk_against_scores(h, 0, k, ms, res.idx, res.score, res.count, tol=REFINED_TOL, gap=REFINED_GAP,
+                                      what=f"degenerate n={n} {variant} k={k} ms={ms}", f64=True, check_tie_order=False)
+            for r in range(n):
+                c = int(res.count[r])
+                assert np.all(res.idx[r, :c] != r) and np.all(res.idx[r, c:] == -1) and np.all(res.score[r, c:] == 0)
+                same = np.diff(res.score[r, :c]) == 0
+                assert np.all(np.diff(res.idx[r, :c])[same] > 0)   # equal float64 scores go by index
+            if ms > 1.0 + 1e-9:
+                assert not res.count.any()
