@@ -321,7 +321,7 @@ def test_config5_one_rank_of_eight_float64_rerank(pkg, device):
     kc = engine.candidate_count(k)
     own, after, before = sharding.column_pieces(me)
     zq = z_all[me.row0:me.row0 + me.rows]
-    ses = engine.TopkSession(zq, me.rows, me.row0, kc, ms - engine.THRESHOLD_BAND)
+    ses = engine.TopkSession(zq, me.rows, me.row0, kc, ms - engine.error_margin(zq.shape[1]))
     ses.accumulate((zq, own[1], own[0]))
     ses.accumulate((z_all[after[0]:], after[1], after[0]), (z_all, before[1], before[0]))
     cand = ses.finish()

@@ -9,6 +9,7 @@ returns without synchronising.
 from __future__ import annotations
 
 import ctypes
+import math
 from dataclasses import dataclass
 
 import torch
@@ -394,8 +395,17 @@ def component_scores(z_all: torch.Tensor, offsets, scales, idx: torch.Tensor, *,
 
 
 # how far below min_similarity the fp32 sweep still collects pairs that refine_min_similarity then
-# decides in float64; the fp32 error of a hybrid score is about 3e-7
+# decides in float64; the fp32 error of a hybrid score is about 3e-7 at 1024 columns
 THRESHOLD_BAND = 2e-6
+
+
+def error_margin(ld: int, base: float = THRESHOLD_BAND) -> float:
+    """The allowance for the fp32 error of a score over rows of ``ld`` floats: ``base`` (2e-6, seven
+    times the largest error seen over the 10^10 pairs of a 100,000 x 1024 catalogue) up to 1024
+    columns, growing with the square root of the row length beyond -- rounding errors of a sum add up
+    like a random walk.  Used as the band below ``min_similarity`` in which the sweeps still collect
+    pairs and as the margin of the re-rank's certification."""
+    return float(base) * max(1.0, math.sqrt(int(ld) / 1024.0))
 
 
 def refine_min_similarity(top: TopK, comp: torch.Tensor, groups, group_weights, min_similarity: float,
@@ -623,7 +633,8 @@ def _band_stage(z, z_q, sources, n, offsets, groups, group_weights, norms, cand,
 def exact_topk(z: torch.Tensor, sources, offsets, groups, group_weights, k: int, min_similarity: float, *,
                n: int | None = None, q_row0: int = 0, nq: int | None = None, cand: TopK | None = None,
                z_q: torch.Tensor | None = None, resweep=None, resweep_k: int | None = None,
-               norms: torch.Tensor | None = None, margin: float = RERANK_MARGIN, band: float = THRESHOLD_BAND, check_finite: bool = True) -> TopK64:
+               norms: torch.Tensor | None = None, margin: float | None = None, band: float | None = None,
+               check_finite: bool = True) -> TopK64:
     """The reference's top-k lists (scripts/populate_database.py:170-218) for shows
     q_row0 .. q_row0 + nq: float64 scores, float64 order, float64 threshold cut.
 
@@ -640,6 +651,8 @@ def exact_topk(z: torch.Tensor, sources, offsets, groups, group_weights, k: int,
     n = z.shape[0] if n is None else int(n)
     nq = n - q_row0 if nq is None else int(nq)
     dev = z.device
+    margin = error_margin(z.shape[1], RERANK_MARGIN) if margin is None else float(margin)
+    band = error_margin(z.shape[1]) if band is None else float(band)
     # one int32 buffer for everything the host reads back: [0] the finite-check word of the norms
     # kernel, [1] the number of flagged shows, [2:] the flagged shows -- one read-back for both
     words = torch.zeros(2 + nq, dtype=torch.int32, device=dev)
@@ -669,7 +682,7 @@ def exact_topk(z: torch.Tensor, sources, offsets, groups, group_weights, k: int,
         flagged = words[1:]
         rescore_topk(sources, n, offsets, groups, group_weights, norms, cand, k, min_similarity, out, q_row0=q_row0,
                      margin=margin, flagged=flagged)
-        bits, nf = words[:2].tolist()
+        bits, nf = words[:2].tolist()  # the one read-back of this stage
         if checked:
             raise_if_not_finite(bits)  # sklearn validates before any arithmetic; nothing was returned yet
         if nf == 0:
