@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--min-similarity", type=float, default=None)
     ap.add_argument("--seed", type=int, default=30001)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather-compare", action="store_true",
+                    help="several GPUs, Z built on every rank: skip the few steps of the all-gather variant timed "
+                         "after the main region (reported as gather_step)")
     ap.add_argument("--no-fp32-compare", action="store_true",
                     help="skip the few fp32-only steps timed after the main region (profiling runs: one kind of step per run)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-to-host measurement (one GPU only)")
@@ -334,6 +337,10 @@ def main():
         x_host = x[:nq].cpu().numpy()
     del x, x_all  # only the stored form stays on the device (for dense rows it is the packed matrix itself)
     z_shard.zero_()  # padding rows of the last shard stay zero
+    # the gathered variant beside a resident-Z run (a few steps after the timed region): its own shard buffer
+    z_shard_g = None
+    if z_local and exact and not args.no_gather_compare:
+        z_shard_g = torch.zeros((shard.per_rank, ld), dtype=torch.float32, device=dev)
 
     def new_out(kk):
         return engine.TopK(torch.empty((nq, kk), dtype=torch.int32, device=dev),
@@ -401,8 +408,8 @@ def main():
     class HostGather:
         """gloo rehearsal: CPU tensors only, copied synchronously to and from the device."""
 
-        def __init__(self):
-            host = z_shard.cpu()
+        def __init__(self, zs):
+            host = zs.cpu()
             parts = [torch.empty_like(host) for _ in range(world)]
             dist.all_gather(parts, host)
             self.full = torch.cat(parts, dim=0)
@@ -416,17 +423,21 @@ def main():
         def wait(self):
             pass
 
-    def start_gather():
+    def start_gather(zs, local):
         if world == 1:
             return None
-        if z_local:
+        if local:
             return Resident()
         if args.backend == "nccl":
-            return dist.all_gather_into_tensor(z_all, z_shard, async_op=True)
-        return HostGather()
+            return dist.all_gather_into_tensor(z_all, zs, async_op=True)
+        return HostGather(zs)
 
-    def step(timed, path_exact=exact):
+    def step(timed, path_exact=exact, gathered=False):
+        """``gathered``: the all-gather variant in a run whose Z is resident (own shard built into
+        z_shard_g, the shards all-gathered into z_all)."""
         marks = []
+        local = z_local and not gathered
+        zs = z_shard_g if gathered else z_shard
 
         def mark(name):
             # phase boundary on the compute stream; an event after work.wait() completes when the
@@ -440,19 +451,19 @@ def main():
         ms_sweep = sweep_min if path_exact else min_sim
         res = out if kk == kc else out_k
         mark("start")
-        if z_local:  # the drop-in's K1 over the stored arrays of all shows
+        if local:  # the drop-in's K1 over the stored arrays of all shows
             engine.assemble_normalize(src_all, args.n, offsets, scales, out=z_all[: args.n])
         elif nq:  # this rank's rows of Z; the others arrive with the all-gather
-            engine.assemble_normalize(src_shard, nq, offsets, scales, out=z_shard[:nq])
+            engine.assemble_normalize(src_shard, nq, offsets, scales, out=zs[:nq])
         mark("k1")
-        work = start_gather()
+        work = start_gather(zs, local)
         if symmetric and world == 1:
             if timed:
                 ev[0].record()
-            engine.cosine_topk_symmetric(z_shard, kk, ms_sweep, n=nq, workspace=workspace, out=res)
+            engine.cosine_topk_symmetric(zs, kk, ms_sweep, n=nq, workspace=workspace, out=res)
             tiles_step[0] = engine.symmetric_tiles(nq, ld, kk, dev)
         elif symmetric:
-            job = sharding.SymmetricShardJob(z_shard, shard, kk, ms_sweep, slots=slots, workspace=workspace,
+            job = sharding.SymmetricShardJob(zs, shard, kk, ms_sweep, slots=slots, workspace=workspace,
                                              colside=side, own_matrix=own_matrix)
             if timed:
                 ev[0].record()
@@ -461,7 +472,7 @@ def main():
             bounds_all = sharding.gather_words(job.own_bounds(), world)
             mark("bounds_gather")
             work.wait()
-            if not z_local:
+            if not local:
                 mark("gather_wait")
             job.phase_half(z_all, bounds_all)
             mark("half")
@@ -473,17 +484,17 @@ def main():
             mark("finish")
             tiles_step[0] = job.tiles
         else:
-            session = engine.TopkSession(z_shard, nq, shard.row0, kk, ms_sweep, slots=slots, workspace=workspace)
+            session = engine.TopkSession(zs, nq, shard.row0, kk, ms_sweep, slots=slots, workspace=workspace)
             if timed:
                 ev[0].record()
             if own_matrix is not None and world > 1:  # own columns: overlaps the all-gather
                 session.accumulate_own_matrix(own_matrix)
             else:
-                session.accumulate((z_shard, own[1], own[0]))
+                session.accumulate((zs, own[1], own[0]))
             mark("own")
             if work is not None:
                 work.wait()
-                if not z_local:
+                if not local:
                     mark("gather_wait")
                 session.accumulate((z_all[after[0]:], after[1], after[0]), (z_all, before[1], before[0]))
                 mark("rest")
@@ -533,13 +544,38 @@ def main():
 
     # per-phase device time (HIP events on the compute stream), averaged over the timed steps, and
     # for several ranks the maximum over the ranks of every phase: where a step's time goes
-    phases = {}
-    for marks in phase_marks:
-        for (_, e0), (name, e1) in zip(marks, marks[1:]):
-            phases[name] = phases.get(name, 0.0) + e0.elapsed_time(e1) / len(phase_marks)
-    if world > 1:
-        phases = {name: max_over_ranks(v) for name, v in phases.items()}
-    phases = {f"{name}_ms": round(v, 4) for name, v in phases.items()}
+    def phases_of(marks_list):
+        acc = {}
+        for marks in marks_list:
+            for (_, e0), (name, e1) in zip(marks, marks[1:]):
+                acc[name] = acc.get(name, 0.0) + e0.elapsed_time(e1) / len(marks_list)
+        if world > 1:
+            acc = {name: max_over_ranks(v) for name, v in acc.items()}
+        return {f"{name}_ms": round(v, 4) for name, v in acc.items()}
+
+    phases = phases_of(phase_marks)
+
+    # several ranks with Z built on every rank: the all-gather variant (own shard, one all-gather of the
+    # shards behind the own block) timed the same way on a few steps, with its phases, beside the main figure
+    gather_step = None
+    if z_shard_g is not None:
+        n_cmp = max(1, min(args.steps, 8))
+        step(False, gathered=True)
+        phase_marks.clear()
+        kept_kernel_ms = list(kernel_ms)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(n_cmp):
+            step(True, gathered=True)
+        barrier()
+        el = max_over_ranks(time.perf_counter() - t1)
+        gather_step = {"ms_per_step": el / n_cmp * 1e3, "value": float(args.n) * float(args.n) * n_cmp / el,
+                       "steps": n_cmp, "phases": phases_of(phase_marks),
+                       "note": "the same exact step with each rank building only its shard of Z and one all-gather "
+                               "of the shards (--z-exchange gather); gather_wait_ms = the part of the all-gather "
+                               "the own block did not hide"}
+        phase_marks.clear()
+        kernel_ms[:] = kept_kernel_ms
 
     # the fp32-only step (lists of the fp32 scores + K5), timed the same way on a few steps, beside the exact one
     fp32_step = None
@@ -627,6 +663,7 @@ def main():
         "phases": phases,
         "rerank": dict(rerank_stats) if exact else None,
         "fp32_step": fp32_step,
+        "gather_step": gather_step,
         "rccl_world": (dist.get_world_size() if world > 1 else 1),
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,

@@ -52,4 +52,8 @@ def test_bench_gpus_2_launches_itself(device, z_exchange):
     assert 0 < line["roofline"]["frac"] <= 1.0
     assert line["config"]["z_exchange"] == ("local" if z_exchange == "auto" else "gather")
     assert ("gather_wait_ms" in line["phases"]) == (z_exchange == "gather")
+    if z_exchange == "auto":  # the all-gather variant is timed beside the resident one, with its own phases
+        assert line["gather_step"]["value"] > 0 and "gather_wait_ms" in line["gather_step"]["phases"]
+    else:
+        assert line["gather_step"] is None
     assert res.stderr.count("lists equal to the plain sweep: True") == 2
