@@ -411,6 +411,16 @@ def test_rccl_route_one_rank_group(pkg, device):
         flag = torch.tensor([3.0], dtype=torch.float64, device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)  # the reduction bench.py uses for its timings
         assert float(flag.item()) == 3.0
+        dist.barrier()
+        # the drop-in's sharded call over RCCL (device tensors in every collective, lists gathered on the device)
+        from tvbingefriend_recommendation_service_amd.ml.similarity_computer import SimilarityComputer
+
+        feats = hybrid_like_blocks(n, seed=77, d_genre=16, d_text=208, as_features=True)
+        sc = SimilarityComputer(0.4, 0.5, 0.1, device=device)
+        single = sc.topk(feats, k=k, min_similarity=ms, variant="populate")
+        sharded = sc.topk(feats, k=k, min_similarity=ms, variant="populate", group=True)
+        for f in ("idx", "score", "count", "comp"):
+            assert np.array_equal(getattr(single, f), getattr(sharded, f)), f
     finally:
         dist.destroy_process_group()
 
