@@ -303,7 +303,7 @@ def main():
     # persistent buffers: the large ones are allocated once, outside the timed region
     exact = args.path == "exact"
     kc = engine.candidate_count(args.k) if exact else args.k       # candidates per show the sweep collects
-    sweep_min = min_sim - engine.error_margin(ld) if exact else min_sim
+    sweep_min = min_sim - engine.error_margin(ld, weights) if exact else min_sim
     # Several ranks: where the stored features of all shows are resident on every rank -- the exact
     # path needs them for the re-rank -- each rank builds the whole normalised matrix itself (K1 over
     # all rows, 0.15 ms at the headline size) and no all-gather of Z is needed; otherwise (or with

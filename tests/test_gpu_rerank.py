@@ -239,3 +239,20 @@ def test_small_and_degenerate_catalogues(pkg, device, n):
                 assert np.all(np.diff(res.idx[r, :c])[same] > 0)   # equal float64 scores go by index
             if ms > 1.0 + 1e-9:
                 assert not res.count.any()
+
+
+@pytest.mark.parametrize("weights", [(4.0, 5.0, 1.0), (6.0, -4.5, 0.3)])
+def test_weights_far_from_a_unit_sum(pkg, device, weights):
+    """The production loop applies the weights as given (scripts/populate_database.py:190-192): scores --
+    and the fp32 error of the sweep's scores -- grow with the weights' magnitudes, and so does the
+    allowance the re-rank certifies with.  Lists are still the float64 oracle's."""
+    n, k = 1500, 20
+    feats = hybrid_like_blocks(n, seed=515, d_genre=24, d_text=300, as_features=True)
+    h, _ = _oracle_hybrid(feats, weights, "populate")
+    ms = float(np.quantile(h, 0.9))
+    res, st = _exact(pkg, device, feats, weights, "populate", k, ms)
+    stats = {}
+    check_topk_against_scores(h, 0, k, ms, res.idx, res.score, res.count, tol=10 * REFINED_TOL, gap=10 * REFINED_GAP,
+                              what=f"weights {weights}", stats=stats, f64=True, check_tie_order=False)
+    print(f"weights {weights}: {stats}, stages {st}")
+    assert stats["exact"] > 0

@@ -399,13 +399,17 @@ def component_scores(z_all: torch.Tensor, offsets, scales, idx: torch.Tensor, *,
 THRESHOLD_BAND = 2e-6
 
 
-def error_margin(ld: int, base: float = THRESHOLD_BAND) -> float:
+def error_margin(ld: int, group_weights=None, base: float = THRESHOLD_BAND) -> float:
     """The allowance for the fp32 error of a score over rows of ``ld`` floats: ``base`` (2e-6, seven
     times the largest error seen over the 10^10 pairs of a 100,000 x 1024 catalogue) up to 1024
     columns, growing with the square root of the row length beyond -- rounding errors of a sum add up
-    like a random walk.  Used as the band below ``min_similarity`` in which the sweeps still collect
-    pairs and as the margin of the re-rank's certification."""
-    return float(base) * max(1.0, math.sqrt(int(ld) / 1024.0))
+    like a random walk -- and with the sum of the weights' magnitudes beyond 1 (``group_weights``: the
+    reference takes any weights, scripts/populate_database.py:190-192 applies them as given, so
+    a score -- and its rounding error -- can be as large as that sum; negative weights do not cancel
+    errors).  Used as the band below ``min_similarity`` in which the sweeps still collect pairs and
+    as the margin of the re-rank's certification."""
+    scale = 1.0 if group_weights is None else max(1.0, float(sum(abs(float(w)) for w in group_weights)))
+    return float(base) * max(1.0, math.sqrt(int(ld) / 1024.0)) * scale
 
 
 def refine_min_similarity(top: TopK, comp: torch.Tensor, groups, group_weights, min_similarity: float,
@@ -651,8 +655,8 @@ def exact_topk(z: torch.Tensor, sources, offsets, groups, group_weights, k: int,
     n = z.shape[0] if n is None else int(n)
     nq = n - q_row0 if nq is None else int(nq)
     dev = z.device
-    margin = error_margin(z.shape[1], RERANK_MARGIN) if margin is None else float(margin)
-    band = error_margin(z.shape[1]) if band is None else float(band)
+    margin = error_margin(z.shape[1], group_weights, RERANK_MARGIN) if margin is None else float(margin)
+    band = error_margin(z.shape[1], group_weights) if band is None else float(band)
     # one int32 buffer for everything the host reads back: [0] the finite-check word of the norms
     # kernel, [1] the number of flagged shows, [2:] the flagged shows -- one read-back for both
     words = torch.zeros(2 + nq, dtype=torch.int32, device=dev)

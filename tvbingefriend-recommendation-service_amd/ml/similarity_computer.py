@@ -311,7 +311,7 @@ class SimilarityComputer:
         engine.assemble_normalize(dev_sources, n, layout.offsets, layout.scales(), out=z_all[:n])
         z_shard = z_all[rank * sh.per_rank:(rank + 1) * sh.per_rank]
         kc = engine.candidate_count(k)
-        floor = min_similarity - engine.error_margin(ld)
+        floor = min_similarity - engine.error_margin(ld, self.group_weights(variant))
         if sharding.symmetric_route_fits(world, kc, ld):
             cand, z_all = sharding.sharded_topk_symmetric_z(z_shard, sh, kc, floor, group=group, z_all=z_all)
         else:

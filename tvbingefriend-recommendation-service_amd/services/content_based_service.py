@@ -179,7 +179,7 @@ class ContentBasedRecommendationService:
         for b in range(layout.nb):
             q[:, layout.offsets[b]:layout.offsets[b + 1]] *= weights[b]
         k = max(n, 1)
-        floor = min_similarity - engine.error_margin(z.shape[1])
+        floor = min_similarity - engine.error_margin(z.shape[1], weights)
         cand = None
         if k <= native.TVBF_MAX_K:
             cand = engine.query_topk(q, z, engine.candidate_count(k), floor, self_index=[row])
