@@ -5,7 +5,8 @@
 
 For every seed: random n, block structure (1-6 blocks in the groups genre / text / metadata),
 stored forms (dense fp32 / fp64 / int64 / bool, CSR fp32 / fp64 with 32- or 64-bit indices), data
-kinds (dense, sparse, few distinct rows = long runs of exactly tied scores, one-hot), weights, K
+kinds (dense, sparse, few distinct rows = long runs of exactly tied scores, one-hot), weights (also
+negative ones and sums far from 1), K
 (also beyond the sweeps' limit) and threshold; now and then short candidate lists so that the
 later stages (band, scan) are taken.  engine.exact_topk must return the lists of the float64
 oracle: the reference's expression (scripts/populate_database.py:180-218) evaluated with the
@@ -85,8 +86,8 @@ def run_seeds(first: int, count: int) -> int:
         kinds = [("dense", "sparse", "few", "onehot")[int(rng.integers(0, 4))] for _ in range(nb)]
         if rng.integers(0, 3) == 0:
             kinds = ["few"] * nb  # whole shows repeat: exact ties in the hybrid score
-        gw = [float(v) for v in rng.choice([0.0, 0.1, 0.25, 0.4, 0.5, 1.0], 3)]
-        if sum(gw) == 0:
+        gw = [float(v) for v in rng.choice([0.0, 0.1, 0.25, 0.4, 0.5, 1.0, 1.0, 3.5, -0.75, -2.0], 3)]
+        if sum(abs(v) for v in gw) == 0:
             gw[0] = 1.0
         k = int(rng.choice([1, 3, 10, 20, 22, 30, 50, 92, 100, 130]))
         ms = float(rng.choice([-1.0, 0.0, 0.1, 0.25, 0.6]))
@@ -115,19 +116,25 @@ def run_seeds(first: int, count: int) -> int:
                 acc = acc + m
             gm.append(acc / len(members) if len(members) > 1 else acc)
         h = (gw[0] * gm[0] + gw[1] * gm[1]) + gw[2] * gm[2]
-        scales = [float(np.sqrt(gw[groups[b]] / gcount[groups[b]])) for b in range(nb)]
-        z = engine.assemble_normalize(sources, n, offsets, scales)
+        per_block = [gw[groups[b]] / gcount[groups[b]] for b in range(nb)]
+        if min(per_block) >= 0:
+            z = engine.assemble_normalize(sources, n, offsets, [float(np.sqrt(w)) for w in per_block])
+            z_q = None
+        else:  # a negative weight has no square root: unit blocks on the column side, the weights on the query side
+            z = engine.assemble_normalize(sources, n, offsets, [1.0] * nb)
+            z_q = engine.assemble_normalize(sources, n, offsets, [float(w) for w in per_block])
         old = engine.BAND_LIST_MAX
         if short_lists:
             engine.BAND_LIST_MAX = int(rng.choice([k + 2, 40, 200]))
         try:
-            top = engine.exact_topk(z, sources, offsets, groups, gw, k, ms, n=n)
+            top = engine.exact_topk(z, sources, offsets, groups, gw, k, ms, n=n, z_q=z_q)
         finally:
             engine.BAND_LIST_MAX = old
         torch.cuda.synchronize()
         idx, score, cnt = (t.cpu().numpy() for t in (top.idx, top.score, top.count))
         stats = {}
-        check_topk_against_scores(h, 0, k, ms, idx, score, cnt, tol=REFINED_TOL, gap=REFINED_GAP,
+        mag = max(1.0, sum(abs(v) for v in gw))  # float64 rounding grows with the scores' magnitude
+        check_topk_against_scores(h, 0, k, ms, idx, score, cnt, tol=mag * REFINED_TOL, gap=mag * REFINED_GAP,
                                   what=f"seed {seed}", stats=stats, f64=True, check_tie_order=False)
         for r in range(n):
             c = int(cnt[r])
