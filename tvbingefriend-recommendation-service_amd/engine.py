@@ -618,20 +618,23 @@ def _band_stage(z, z_q, sources, n, offsets, groups, group_weights, norms, cand,
     thousand tied shows): they go on to the scan."""
     dev = z.device
     left = []
-    nf = int(rows.numel())
-    cap = int(max(k + 1, min(BAND_LIST_MAX, BAND_BYTES // (8 * max(nf, 1)))))
-    local = rows.long() - q_row0
-    zq = z.index_select(0, rows.long()) if z_q is None else z_q.index_select(0, local)
-    floor = torch.full((nf,), min_similarity - band, dtype=torch.float32, device=dev)
-    t = torch.maximum(floor, cand.score.index_select(0, local)[:, k - 1] - 2.0 * float(margin)).contiguous()
-    idx, score, cnt = band_candidates(z, zq, t, cap, n=n)
-    over = cnt >= cap  # more shows in the band than the list takes: not decided here
-    count = torch.where(over, torch.zeros_like(cnt), cnt)
-    rescore_topk(sources, n, offsets, groups, group_weights, norms, TopK(idx, score, count), k, min_similarity, out,
-                 q_row0=q_row0, row_ids=rows, margin=margin)
-    if not bool(over.any().item()):  # the usual case: one scalar read back, no compaction
-        return rows[:0]
-    return rows[over].contiguous()
+    cap = int(max(k + 1, BAND_LIST_MAX))
+    chunk = max(1, BAND_BYTES // (8 * cap))  # shows per launch: their (column, score) buffers stay within BAND_BYTES
+    for r0 in range(0, int(rows.numel()), chunk):
+        part = rows[r0:r0 + chunk]
+        nf = int(part.numel())
+        local = part.long() - q_row0
+        zq = z.index_select(0, part.long()) if z_q is None else z_q.index_select(0, local)
+        floor = torch.full((nf,), min_similarity - band, dtype=torch.float32, device=dev)
+        t = torch.maximum(floor, cand.score.index_select(0, local)[:, k - 1] - 2.0 * float(margin)).contiguous()
+        idx, score, cnt = band_candidates(z, zq, t, cap, n=n)
+        over = cnt >= cap  # more shows in the band than the list takes: not decided here
+        count = torch.where(over, torch.zeros_like(cnt), cnt)
+        rescore_topk(sources, n, offsets, groups, group_weights, norms, TopK(idx, score, count), k, min_similarity,
+                     out, q_row0=q_row0, row_ids=part.contiguous(), margin=margin)
+        if bool(over.any().item()):  # rare; the usual case reads one scalar back, no compaction
+            left.append(part[over])
+    return torch.cat(left).contiguous() if left else rows[:0]
 
 
 def exact_topk(z: torch.Tensor, sources, offsets, groups, group_weights, k: int, min_similarity: float, *,
