@@ -48,7 +48,8 @@ extern "C" {
 #define TVBF_E_BUSY (-4)      /* the library-owned scratch of this GPU is in use  */
 
 #define TVBF_MAX_BLOCKS 8 /* feature blocks per row (genre, text, platform, ...) */
-#define TVBF_MAX_K 100    /* neighbours per show (bounded by the 160 KiB LDS of a CU) */
+#define TVBF_MAX_K 116    /* neighbours per show: 100 + the 16 extra candidates a float64 re-rank of 100 asks for
+                              (bounded by the 160 KiB LDS of a CU: two workgroups of the fused kernel up to 127) */
 
 /* Library version: major*10000 + minor*100 + patch. */
 int tvbf_version(void);

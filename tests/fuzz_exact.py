@@ -89,7 +89,7 @@ def run_seeds(first: int, count: int) -> int:
         gw = [float(v) for v in rng.choice([0.0, 0.1, 0.25, 0.4, 0.5, 1.0, 1.0, 3.5, -0.75, -2.0], 3)]
         if sum(abs(v) for v in gw) == 0:
             gw[0] = 1.0
-        k = int(rng.choice([1, 3, 10, 20, 22, 30, 50, 92, 100, 130]))
+        k = int(rng.choice([1, 3, 10, 20, 22, 30, 50, 92, 100, 108, 116, 130]))
         ms = float(rng.choice([-1.0, 0.0, 0.1, 0.25, 0.6]))
         short_lists = int(rng.integers(0, 4)) == 0
         print(f"seed {seed}: n={n} blocks={list(zip(groups, widths, kinds))} w={gw} k={k} min={ms}"

@@ -76,7 +76,7 @@ def run_seeds(first: int, count: int, big: bool = False) -> int:
         kind = ("dense", "hybrid", "few", "onehot")[int(rng.integers(0, 4))]
         n = int(rng.choice([5000, 8200, 12000, 20000] if big else [130, 257, 640, 1000, 1921, 2500, 4097, 6000]))
         d = int(rng.choice([64, 576, 1024, 2048] if big else [32, 64, 96, 128, 192, 256, 320, 512]))
-        k = int(rng.choice([1, 2, 5, 10, 20, 30, 31, 50, 100]))
+        k = int(rng.choice([1, 2, 5, 10, 20, 30, 31, 50, 100, 116]))
         ms = float(rng.choice([-1.0, 0.0, 0.1, 0.3]))
         print(f"seed {seed}: {kind} n={n} d={d} k={k} min={ms}", end=" ", flush=True)
         x = make_rows(rng, kind, n, d)

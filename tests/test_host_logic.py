@@ -54,7 +54,7 @@ def test_argument_validation_needs_no_gpu(pkg):
     rc = lib.tvbf_upper_tri_stats_f64(p, 1, 1, p, p, 1 << 20, None)
     assert rc == -1 and b"empty" in lib.tvbf_last_error()
     assert lib.tvbf_topk_workspace_bytes(0, 10, 32, 5) == 0
-    assert lib.tvbf_topk_workspace_bytes(10, 10, 32, 101) == 0
+    assert lib.tvbf_topk_workspace_bytes(10, 10, 32, 117) == 0
     assert lib.tvbf_topk_workspace_bytes(1000, 1000, 32, 20) >= 1000 * 20 * 8
 
 
@@ -574,7 +574,8 @@ def test_catalogue_route_is_bounded_by_available_memory():
     with pytest.raises(MemoryError):
         engine.choose_catalogue_route(9 * gib, 2 * gib, 1 * gib)
     assert engine.candidate_count(20) == 28 and engine.candidate_count(22) == 30
-    assert engine.candidate_count(23) == 39 and engine.candidate_count(90) == 100 and engine.candidate_count(100) == 100
+    assert engine.candidate_count(23) == 39 and engine.candidate_count(90) == 106 and engine.candidate_count(100) == 116
+    assert engine.candidate_count(110) == 116 and engine.candidate_count(116) == 116
 
 
 @pytest.mark.parametrize("world,per,k", [(2, 5, 3), (3, 4, 2), (8, 7, 20)])

@@ -65,7 +65,7 @@ SYMBOLS = (
 )
 
 TVBF_MAX_BLOCKS = 8
-TVBF_MAX_K = 100
+TVBF_MAX_K = 116
 TVBF_MAX_SOURCES = 8
 TVBF_MAX_QUERIES = 64
 TVBF_STATIC_SCRATCH_BYTES = 32 << 20
