@@ -259,7 +259,8 @@ def test_config3_100k_x_1024_every_row_against_float64(pkg, device, k, ms, kind)
     print(f"config 3, K={k} {kind}: {ranks} ranks compared, {exact} by index, max score error {max_err:.2e}")
 
 
-@pytest.mark.parametrize("k,ms,kind", [(20, 0.1, "hybrid"), (50, 0.1, "hybrid"), (20, -1.0, "dense")])
+@pytest.mark.parametrize("k,ms,kind", [(20, 0.1, "hybrid"), (50, 0.1, "hybrid"), (20, -1.0, "dense"),
+                                       (100, 0.1, "hybrid")])
 def test_config3_float64_rerank_every_row(pkg, device, k, ms, kind):
     """BASELINE config #3 at full size through the float64 re-rank (engine.exact_topk: fp32 sweep
     for k + 8 / k + 16 candidates, float64 scores from the stored rows, longer lists or a scan for the
