@@ -12,11 +12,14 @@
 //
 //   block_norms_f64_kernel   per show and block the float64 L2 norm with sklearn's zero guard
 //   rescore_topk_kernel      one workgroup per show: its row as float64 in LDS (divided by its
-//                            norms), the candidates dealt out to four wavefronts -- one gather of
-//                            a candidate's stored entries each --, ranking by counting, outputs, flag
+//                            norms), the candidates dealt out to the lane groups of four wavefronts
+//                            (eight lanes per candidate: eight gathers of stored entries in flight
+//                            per wavefront), ranking by counting, outputs, flag
 //   score_rows_f64_kernel    the float64 score of a few shows against ALL shows (the last resort
 //                            for a flagged row: tvbf_dense_rows_topk_f64 then selects exactly)
-// All three are bound by the gather of the candidates' rows (HBM / L2), not by arithmetic.
+// All three are bound by the latency of the gathers of the candidates' rows (the stored arrays of a
+// catalogue fit the on-die caches; wavefronts spend three quarters of their time waiting for
+// loads), not by bandwidth or arithmetic.
 
 #include <hip/hip_runtime.h>
 #include <float.h>
